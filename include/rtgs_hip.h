@@ -1,0 +1,173 @@
+/*
+ * rtgs_hip.h -- C ABI of the MI355X (gfx950) ray-traced Gaussian-splat render path.
+ *
+ * This is the drop-in boundary for ONE hot path of fangjunzhou/rt-gaussian-splat-renderer
+ * (reference @ 2025-06-29): camera ray generation -> quaternion+scale -> covariance ->
+ * ray/ellipsoid intersection -> per-ray depth sort -> front-to-back alpha compositing.
+ * The reference has no FFI of its own: its operator boundary is "Python host object ->
+ * @ti.kernel launch".  Each entry point below names the reference kernel / @ti.func it
+ * replaces (paths relative to the reference's src/rtgs/).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / HIP types in the signatures
+ *     (rtgs_stream_t is a hipStream_t passed as void*; NULL = the default stream).
+ *   - every pointer is a DEVICE pointer on the current device unless it is a small
+ *     parameter struct (RtgsScene / RtgsCamera / RtgsTraceParams: host structs, by pointer).
+ *   - the caller owns every buffer; the library never allocates, copies to the host or
+ *     synchronises (graph-capture safe).  Work is ordered on the caller's stream.
+ *   - stateless and re-entrant; return 0 on success, a negative RTGS_E* code otherwise.
+ *   - quaternions are scalar-last (x, y, z, w) (utils/quaternion.py); image buffers are
+ *     indexed [i][j], i = x in [0, W), j = y in [0, H), (0,0) bottom-left, j fastest in
+ *     memory (the (W, H) Taichi field of camera.py:29 / ray_tracer.py:33-37).
+ *   - fp32 in, fp32 out; indices int32.
+ */
+#ifndef RTGS_HIP_H
+#define RTGS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTGS_ABI_VERSION 1
+#define RTGS_MAX_DEPTH 16        /* peels kept per ray in one pass (__main__.py:70 default) */
+#define RTGS_TILE 32             /* macro-tile edge in pixels: the unit of sharding */
+#define RTGS_RAY_FLOATS 8        /* Ray = origin3, direction3, start, end (ray.py:4-18) */
+#define RTGS_SH_COEFFS 15        /* sh_10 .. sh_36 (gaussian.py:41-55) */
+
+enum {
+  RTGS_OK = 0,
+  RTGS_EINVAL = -1,      /* NULL pointer, non-positive size, bad enum */
+  RTGS_EDEPTH = -2,      /* depth outside [1, RTGS_MAX_DEPTH] */
+  RTGS_EWORKSPACE = -3,  /* workspace smaller than rtgs_workspace_bytes() */
+  RTGS_ELAUNCH = -4,     /* hipGetLastError() after a launch was not hipSuccess */
+  RTGS_EDEVICE = -5      /* no usable gfx950 device / runtime error */
+};
+
+typedef void* rtgs_stream_t;
+
+/* Gaussians, structure-of-arrays in HBM.  Values are post-activation, i.e. exactly what
+ * Gaussian.init takes (gaussian.py:59-84): what Scene.load_file produces at scene.py:110-114. */
+typedef struct RtgsScene {
+  int32_t n;
+  const float* position;      /* [n][3]  Gaussian.position                         */
+  const float* cov_inv6;      /* [n][6]  inverse covariance xx,xy,xz,yy,yz,zz      */
+                              /*         (rtgs_covariance output)                  */
+  const float* color_opacity; /* [n][4]  Gaussian.color rgb, Gaussian.opacity      */
+  const float* sh;            /* [n][15][3] sh_10..sh_36, or NULL (all zero)       */
+} RtgsScene;
+
+/* Camera(position, rotation, buf_size, focal_length), camera.py:17-29. */
+typedef struct RtgsCamera {
+  float position[3];
+  float rotation[4];          /* xyzw */
+  int32_t width, height;      /* buf_size; sensor size == buf_size (camera.py:26) */
+  float fx, fy;               /* focal_length, in pixels */
+} RtgsCamera;
+
+/* flags for RtgsTraceParams.flags */
+#define RTGS_TRACE_RESUME 1u      /* read per-pixel ray.start and attenuation (a partial sample
+                                     in progress); otherwise start = 0, attenuation = 1      */
+#define RTGS_TRACE_ACCUMULATE 2u  /* sample_buf += radiance (ray_tracer.py:95); otherwise the
+                                     shard's pixels are overwritten                          */
+#define RTGS_TRACE_COMPACT 4u     /* sample_buf is the shard-compact [local_tile][32][32][3]
+                                     buffer that rtgs_untile scatters, not the (W,H,3) image  */
+
+typedef struct RtgsTraceParams {
+  int32_t depth;        /* peels performed by this call, 1..RTGS_MAX_DEPTH               */
+  float t_cutoff;       /* transmittance early-out of the compositing loop; 0 = disabled  */
+                        /* (the reference has none)                                       */
+  int32_t tile_first;   /* this shard renders macro-tiles tile_first, +tile_step, ...     */
+  int32_t tile_step;    /* (rank, world_size); (0, 1) = whole frame                       */
+  uint32_t flags;
+} RtgsTraceParams;
+
+int rtgs_abi_version(void);
+const char* rtgs_strerror(int code);
+
+/* Gaussian.cov (gaussian.py:86-102) with quat.as_rotation_mat3 (utils/quaternion.py:99-121):
+ * Sigma = R S S^T R^T per Gaussian, and its inverse (the ti.math.inverse of gaussian.py:196,215,
+ * evaluated as R S^-2 R^T).  cov6 may be NULL.  Layout xx,xy,xz,yy,yz,zz. */
+int rtgs_covariance(int32_t n, const float* rotation /*[n][4]*/, const float* scale /*[n][3]*/,
+                    float* cov6 /*[n][6] or NULL*/, float* cov_inv6 /*[n][6]*/,
+                    rtgs_stream_t stream);
+
+/* Camera.generate_ray_field (camera.py:57-71): rays[(i*H + j)*8 ..] = {o, d, 0, +inf}. */
+int rtgs_generate_rays(const RtgsCamera* cam, float* rays /*[W][H][8]*/, rtgs_stream_t stream);
+
+/* Bytes of scratch rtgs_trace needs for n Gaussians (per-frame projected records). */
+size_t rtgs_workspace_bytes(int32_t n);
+
+/* Number of 32x32 macro-tiles of a W x H image, and how many of them a shard owns. */
+int32_t rtgs_num_tiles(int32_t width, int32_t height);
+int32_t rtgs_num_local_tiles(int32_t width, int32_t height, int32_t tile_first, int32_t tile_step);
+
+/* RayTracer.sample_step x depth (ray_tracer.py:39-54, 79-104) with Scene.hit's closest-hit
+ * semantics (scene.py:433-437), Gaussian.hit (gaussian.py:203-230), Gaussian.eval / eval_sh
+ * (gaussian.py:140-201) and the clear_attenuation + generate_ray_field of step 0, in one pass:
+ * per pixel, the `depth` nearest entry distances t1 > ray.start are found, sorted and
+ * composited front to back.
+ *   sample_buf       [W][H][3]  (or compact, see RTGS_TRACE_COMPACT)
+ *   attenuation_buf  [W][H]     in (RESUME) / out; may be NULL without RESUME
+ *   ray_start        &rays[0][0][6] with stride 8 floats, i.e. cam_ray_field[i,j].start,
+ *                    in (RESUME) / out (t1 of the last peel + 1e-8, or +inf after a miss);
+ *                    may be NULL without RESUME.  ray_start_stride in floats (8 for a Ray
+ *                    field, 1 for a plain [W][H] plane).
+ * Runs the per-frame projection (rtgs_project) first unless `projected` is non-zero. */
+int rtgs_trace(const RtgsScene* scene, const RtgsCamera* cam, const RtgsTraceParams* params,
+               float* sample_buf, float* attenuation_buf, float* ray_start,
+               int32_t ray_start_stride, void* workspace, size_t workspace_bytes,
+               int32_t projected, rtgs_stream_t stream);
+
+/* The per-frame half of rtgs_trace on its own: camera-relative conic records and screen
+ * bounds of every Gaussian into the workspace (quaternion -> covariance -> ray/ellipsoid
+ * quadratic of gaussian.py:215-219, factored per Gaussian instead of per ray). */
+int rtgs_project(const RtgsScene* scene, const RtgsCamera* cam, void* workspace,
+                 size_t workspace_bytes, rtgs_stream_t stream);
+
+/* Tile-parallel epilogue: scatter gathered shard-compact buffers
+ * compact[rank][local_tile][32][32][3] (rank-major, `tiles_per_rank` tiles each, as produced
+ * by RTGS_TRACE_COMPACT with (tile_first, tile_step) = (rank, world)) into image [W][H][3]. */
+int rtgs_untile(const float* compact, int32_t world, int32_t tiles_per_rank, int32_t width,
+                int32_t height, float* image, rtgs_stream_t stream);
+
+/* Scene.hit (scene.py:406-450) for a batch of arbitrary rays: brute-force closest hit,
+ * argmin t1 subject to ray.start < t1 < ray.end; lowest index wins exact ties.
+ *   rays [n_rays][8]; hit_idx [n_rays] (-1 = miss); hit_t [n_rays][2] = (t1, t2), +inf on miss. */
+int rtgs_closest_hit(const RtgsScene* scene, int32_t n_rays, const float* rays,
+                     int32_t* hit_idx, float* hit_t, rtgs_stream_t stream);
+
+/* Gaussian.hit (gaussian.py:203-230), elementwise: ray k against Gaussian k. */
+int rtgs_gaussian_hit(int32_t n, const float* rays /*[n][8]*/, const float* position /*[n][3]*/,
+                      const float* cov_inv6 /*[n][6]*/, float* hit_t /*[n][2]*/,
+                      rtgs_stream_t stream);
+
+/* Gaussian.eval (gaussian.py:183-201) incl. eval_sh (gaussian.py:140-181), elementwise:
+ * out[k] = (rgb, alpha) of Gaussian k at pos[k] seen along dir[k].  sh may be NULL. */
+int rtgs_gaussian_eval(int32_t n, const float* pos /*[n][3]*/, const float* dir /*[n][3]*/,
+                       const float* position, const float* cov_inv6, const float* color_opacity,
+                       const float* sh, float* out /*[n][4]*/, rtgs_stream_t stream);
+
+/* quat.mul / conj / rot_vec3 / as_rotation_mat3 (utils/quaternion.py:8-35, 84-121), batched.
+ * op: 0 mul(p,q)->[n][4]; 1 conj(p)->[n][4]; 2 rot_vec3(p, q.xyz)->[n][3];
+ *     3 as_rotation_mat3(p)->[n][9] row-major.  q is [n][4] (ignored for 1 and 3). */
+int rtgs_quat_op(int32_t op, int32_t n, const float* p, const float* q, float* out,
+                 rtgs_stream_t stream);
+
+/* Ray.get (ray.py:43-52): out[k] = o_k + t_k d_k. */
+int rtgs_ray_get(int32_t n, const float* rays /*[n][8]*/, const float* t /*[n]*/,
+                 float* out /*[n][3]*/, rtgs_stream_t stream);
+
+/* RayTracer.generate_disp_buffer (ray_tracer.py:68-77): disp = sample / (ns + nst/nd). */
+int rtgs_disp_buffer(int32_t n_pixels, const float* sample_buf, int32_t num_samples,
+                     int32_t num_steps, int32_t num_depth, float* disp_buf, rtgs_stream_t stream);
+
+/* RayTracer.clear_sample / clear_attenuation (ray_tracer.py:56-66): fill n floats. */
+int rtgs_fill(float* dst, size_t n, float value, rtgs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTGS_HIP_H */

@@ -1,0 +1,360 @@
+// rtgs_ops.hip -- the small kernels either side of the trace: covariance precompute, camera ray
+// field, batched Scene.hit, and the elementwise device mirrors of the reference's @ti.func
+// primitives (used by the Python API objects and by the parity tests).
+//
+// Reference (paths relative to its src/rtgs/): gaussian.py:86-102 (cov), camera.py:31-71,
+// scene.py:406-450 (criteria :433-437), gaussian.py:140-230, utils/quaternion.py:8-121,
+// ray.py:43-52, ray_tracer.py:56-77.
+#include "rtgs_common.hpp"
+
+namespace rtgs {
+namespace {
+
+inline int check_launch() { return hipGetLastError() == hipSuccess ? RTGS_OK : RTGS_ELAUNCH; }
+inline dim3 grid_for(size_t n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
+
+// ---- Gaussian.cov + inverse ---------------------------------------------------------
+// Sigma = R S S^T R^T (gaussian.py:100-101); Sigma^-1 = R S^-2 R^T / |q|^8 because the
+// reference's R is |q|^2 times a rotation (utils/quaternion.py:99-121).  fp64 inside so the
+// stored fp32 values are correctly rounded.
+__global__ __launch_bounds__(256) void k_covariance(int32_t n, const float* __restrict__ rot,
+                                                     const float* __restrict__ scale,
+                                                     float* __restrict__ cov6,
+                                                     float* __restrict__ cov_inv6) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  const double q[4] = {rot[4 * g], rot[4 * g + 1], rot[4 * g + 2], rot[4 * g + 3]};
+  const double s[3] = {scale[3 * g], scale[3 * g + 1], scale[3 * g + 2]};
+  double R[9];
+  quat_to_mat3(q, R);
+  const double k2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  const double k8 = (k2 * k2) * (k2 * k2);
+  const double s2[3] = {s[0] * s[0], s[1] * s[1], s[2] * s[2]};
+  const double is2[3] = {1.0 / (s2[0] * k8), 1.0 / (s2[1] * k8), 1.0 / (s2[2] * k8)};
+  int o = 0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = i; j < 3; ++j) {
+      double c = 0.0, ci = 0.0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        c += R[3 * i + k] * s2[k] * R[3 * j + k];
+        ci += R[3 * i + k] * is2[k] * R[3 * j + k];
+      }
+      if (cov6) cov6[6 * g + o] = (float)c;
+      cov_inv6[6 * g + o] = (float)ci;
+      ++o;
+    }
+  }
+}
+
+// ---- Camera.generate_ray_field (camera.py:57-71), literal fp32 ------------------------
+__global__ __launch_bounds__(256) void k_generate_rays(RtgsCamera cam, float* __restrict__ rays) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= cam.width * cam.height) return;
+  const int i = p / cam.height, j = p % cam.height;
+  const float W = (float)cam.width, H = (float)cam.height;
+  const float u = ((float)i + 0.5f) / W;
+  const float v = ((float)j + 0.5f) / H;
+  const float px = (W * u - 0.5f * W) / cam.fx;
+  const float py = (H * v - 0.5f * H) / cam.fy;
+  const float inv = 1.0f / sqrtf(px * px + py * py + 1.0f);
+  const float dc[3] = {px * inv, py * inv, -inv};
+  float dw[3];
+  quat_rot_vec3(cam.rotation, dc, dw);
+  float* r = rays + (size_t)p * RTGS_RAY_FLOATS;
+  float4* r4 = reinterpret_cast<float4*>(r);
+  r4[0] = make_float4(cam.position[0], cam.position[1], cam.position[2], dw[0]);
+  r4[1] = make_float4(dw[1], dw[2], 0.f, kInf);  // ray.py:20-41: start 0, end inf
+}
+
+// ---- ray/ellipsoid quadratic, gaussian.py:203-230, fp64 inside -------------------------
+struct HitD { double t1, t2; };
+
+__device__ __forceinline__ HitD hit_quadratic(const double o[3], const double d[3], const float* mu,
+                                              const float* ci) {
+  const double inf = __builtin_huge_val();
+  const double mx = o[0] - (double)mu[0], my = o[1] - (double)mu[1], mz = o[2] - (double)mu[2];
+  const double Mxx = ci[0], Mxy = ci[1], Mxz = ci[2], Myy = ci[3], Myz = ci[4], Mzz = ci[5];
+  const double Md0 = Mxx * d[0] + Mxy * d[1] + Mxz * d[2];
+  const double Md1 = Mxy * d[0] + Myy * d[1] + Myz * d[2];
+  const double Md2 = Mxz * d[0] + Myz * d[1] + Mzz * d[2];
+  const double Mm0 = Mxx * mx + Mxy * my + Mxz * mz;
+  const double Mm1 = Mxy * mx + Myy * my + Myz * mz;
+  const double Mm2 = Mxz * mx + Myz * my + Mzz * mz;
+  const double A = d[0] * Md0 + d[1] * Md1 + d[2] * Md2;
+  const double B = 2.0 * (d[0] * Mm0 + d[1] * Mm1 + d[2] * Mm2);
+  const double C = mx * Mm0 + my * Mm1 + mz * Mm2 - 3.0;  // BOUNDING_THRESHOLD, gaussian.py:13
+  const double delta = B * B - 4.0 * A * C;
+  HitD h{inf, inf};
+  if (delta > 0.0) {
+    const double sq = sqrt(delta);
+    h.t1 = (-B - sq) / (2.0 * A);
+    h.t2 = (-B + sq) / (2.0 * A);
+  } else if (delta == 0.0) {
+    h.t1 = -B / (2.0 * A);
+  }
+  return h;
+}
+
+// ---- Scene.hit for a batch of arbitrary rays (scene.py:406-450) ------------------------
+// One thread per ray; the workgroup streams (position, inverse covariance) = 36 B/Gaussian
+// through LDS in slabs.  Brute force: the BVH of the reference only accelerates this query.
+constexpr int kHitBlock = 256;
+__global__ __launch_bounds__(kHitBlock) void k_closest_hit(int32_t n, const float* __restrict__ pos,
+                                                            const float* __restrict__ ci6,
+                                                            int32_t n_rays,
+                                                            const float* __restrict__ rays,
+                                                            int32_t* __restrict__ hit_idx,
+                                                            float* __restrict__ hit_t) {
+  __shared__ float s_g[kHitBlock * 9];
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = r < n_rays;
+  double o[3] = {0, 0, 0}, d[3] = {0, 1, 0};
+  float start = 0.f, end = kInf;
+  if (live) {
+    const float* rp = rays + (size_t)r * RTGS_RAY_FLOATS;
+    o[0] = rp[0]; o[1] = rp[1]; o[2] = rp[2];
+    d[0] = rp[3]; d[1] = rp[4]; d[2] = rp[5];
+    start = rp[6]; end = rp[7];
+  }
+  const double inf = __builtin_huge_val();
+  double best_t = inf, best_t2 = inf;
+  int best = -1;
+  for (int base = 0; base < n; base += kHitBlock) {
+    const int cnt = min(kHitBlock, n - base);
+    __syncthreads();
+    if ((int)threadIdx.x < cnt) {
+      const int g = base + threadIdx.x;
+      float* s = s_g + threadIdx.x * 9;
+      s[0] = pos[3 * g]; s[1] = pos[3 * g + 1]; s[2] = pos[3 * g + 2];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) s[3 + k] = ci6[6 * g + k];
+    }
+    __syncthreads();
+    if (live) {
+      for (int k = 0; k < cnt; ++k) {
+        const float* s = s_g + k * 9;
+        const HitD h = hit_quadratic(o, d, s, s + 3);
+        // scene.py:433-436: start < t1 < end, strictly smaller than the best so far
+        if (h.t1 < (double)end && h.t1 > (double)start && h.t1 < best_t) {
+          best_t = h.t1; best_t2 = h.t2; best = base + k;
+        }
+      }
+    }
+  }
+  if (live) {
+    hit_idx[r] = best;
+    hit_t[2 * r] = (float)best_t;
+    hit_t[2 * r + 1] = (float)best_t2;
+  }
+}
+
+// ---- Gaussian.hit, elementwise ----------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gaussian_hit(int32_t n, const float* __restrict__ rays,
+                                                       const float* __restrict__ pos,
+                                                       const float* __restrict__ ci6,
+                                                       float* __restrict__ hit_t) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const float* rp = rays + (size_t)k * RTGS_RAY_FLOATS;
+  const double o[3] = {rp[0], rp[1], rp[2]};
+  const double d[3] = {rp[3], rp[4], rp[5]};
+  const HitD h = hit_quadratic(o, d, pos + 3 * (size_t)k, ci6 + 6 * (size_t)k);
+  hit_t[2 * k] = (float)h.t1;
+  hit_t[2 * k + 1] = (float)h.t2;
+}
+
+// ---- Gaussian.eval + eval_sh (gaussian.py:140-201), elementwise, fp64 inside -------------
+__global__ __launch_bounds__(256) void k_gaussian_eval(int32_t n, const float* __restrict__ pos,
+                                                        const float* __restrict__ dir,
+                                                        const float* __restrict__ mu,
+                                                        const float* __restrict__ ci6,
+                                                        const float* __restrict__ colop,
+                                                        const float* __restrict__ sh,
+                                                        float* __restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const double x = (double)pos[3 * k] - mu[3 * k], y = (double)pos[3 * k + 1] - mu[3 * k + 1],
+               z = (double)pos[3 * k + 2] - mu[3 * k + 2];
+  const float* c = ci6 + 6 * (size_t)k;
+  const double q = x * (c[0] * x + c[1] * y + c[2] * z) + y * (c[1] * x + c[3] * y + c[4] * z) +
+                   z * (c[2] * x + c[4] * y + c[5] * z);
+  const double rho = exp(-q);  // no 1/2 factor: gaussian.py:197
+  double rgb[3] = {colop[4 * k], colop[4 * k + 1], colop[4 * k + 2]};
+  if (sh) {
+    double dx = dir[3 * k], dy = dir[3 * k + 1], dz = dir[3 * k + 2];
+    const double il = 1.0 / sqrt(dx * dx + dy * dy + dz * dz);  // gaussian.py:200
+    dx *= il; dy *= il; dz *= il;
+    const double c0 = sqrt(3.0 / M_PI), c1 = sqrt(15.0 / M_PI), c2 = sqrt(5.0 / M_PI),
+                 c3 = sqrt(35.0 / (2.0 * M_PI)), c4 = sqrt(105.0 / M_PI),
+                 c5 = sqrt(21.0 / (2.0 * M_PI)), c6 = sqrt(7.0 / M_PI);
+    const double Y[RTGS_SH_COEFFS] = {
+        0.5 * c0 * dy, 0.5 * c0 * dz, 0.5 * c0 * dx, 0.5 * c1 * dx * dy, 0.5 * c1 * dy * dz,
+        0.25 * c2 * (3 * dz * dz - 1), 0.5 * c1 * dx * dz, 0.25 * c1 * (dx * dx - dy * dy),
+        0.25 * c3 * dy * (3 * dx * dx - dy * dy), 0.5 * c4 * dx * dy * dz,
+        0.25 * c5 * dy * (5 * dz * dz - 1), 0.25 * c6 * (5 * dz * dz - 3 * dz) /* sic, :160 */,
+        0.25 * c5 * dx * (5 * dz * dz - 1), 0.25 * c4 * (dx * dx - dy * dy) * dz,
+        0.25 * c3 * dx * (dx * dx - 3 * dy * dy)};
+    const float* s = sh + (size_t)k * RTGS_SH_COEFFS * 3;
+    for (int b = 0; b < RTGS_SH_COEFFS; ++b) {
+      rgb[0] += Y[b] * s[3 * b]; rgb[1] += Y[b] * s[3 * b + 1]; rgb[2] += Y[b] * s[3 * b + 2];
+    }
+  }
+  out[4 * k] = (float)rgb[0]; out[4 * k + 1] = (float)rgb[1]; out[4 * k + 2] = (float)rgb[2];
+  out[4 * k + 3] = (float)((double)colop[4 * k + 3] * rho);
+}
+
+// ---- quaternion helpers, literal fp32 (utils/quaternion.py) -------------------------------
+__global__ __launch_bounds__(256) void k_quat_op(int32_t op, int32_t n, const float* __restrict__ p,
+                                                  const float* __restrict__ q,
+                                                  float* __restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const float pp[4] = {p[4 * k], p[4 * k + 1], p[4 * k + 2], p[4 * k + 3]};
+  if (op == 0) {
+    const float qq[4] = {q[4 * k], q[4 * k + 1], q[4 * k + 2], q[4 * k + 3]};
+    float r[4];
+    quat_mul(pp, qq, r);
+    for (int c = 0; c < 4; ++c) out[4 * k + c] = r[c];
+  } else if (op == 1) {
+    float r[4];
+    quat_conj(pp, r);
+    for (int c = 0; c < 4; ++c) out[4 * k + c] = r[c];
+  } else if (op == 2) {
+    const float v[3] = {q[4 * k], q[4 * k + 1], q[4 * k + 2]};
+    float r[3];
+    quat_rot_vec3(pp, v, r);
+    for (int c = 0; c < 3; ++c) out[3 * k + c] = r[c];
+  } else {
+    // as_rotation_mat3: column c = q e_c q* via the same two products the reference runs
+    for (int c = 0; c < 3; ++c) {
+      float e[3] = {0.f, 0.f, 0.f};
+      e[c] = 1.f;
+      float r[3];
+      quat_rot_vec3(pp, e, r);
+      out[9 * k + 0 + c] = r[0]; out[9 * k + 3 + c] = r[1]; out[9 * k + 6 + c] = r[2];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_ray_get(int32_t n, const float* __restrict__ rays,
+                                                  const float* __restrict__ t,
+                                                  float* __restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const float* r = rays + (size_t)k * RTGS_RAY_FLOATS;
+  for (int c = 0; c < 3; ++c) out[3 * k + c] = r[c] + t[k] * r[3 + c];  // ray.py:52
+}
+
+__global__ __launch_bounds__(256) void k_disp(size_t n, const float* __restrict__ sample, float denom,
+                                               float* __restrict__ disp) {
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) disp[k] = sample[k] / denom;  // ray_tracer.py:76-77
+}
+
+__global__ __launch_bounds__(256) void k_fill(float* __restrict__ dst, size_t n, float value) {
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) dst[k] = value;
+}
+
+}  // namespace
+}  // namespace rtgs
+
+using namespace rtgs;
+
+extern "C" {
+
+int rtgs_abi_version(void) { return RTGS_ABI_VERSION; }
+
+const char* rtgs_strerror(int code) {
+  switch (code) {
+    case RTGS_OK: return "ok";
+    case RTGS_EINVAL: return "invalid argument (null pointer, non-positive size or bad enum)";
+    case RTGS_EDEPTH: return "depth outside [1, RTGS_MAX_DEPTH]";
+    case RTGS_EWORKSPACE: return "workspace smaller than rtgs_workspace_bytes()";
+    case RTGS_ELAUNCH: return "HIP kernel launch failed";
+    case RTGS_EDEVICE: return "no usable HIP device";
+    default: return "unknown rtgs error";
+  }
+}
+
+int rtgs_covariance(int32_t n, const float* rotation, const float* scale, float* cov6,
+                    float* cov_inv6, rtgs_stream_t stream) {
+  if (n <= 0 || !rotation || !scale || !cov_inv6) return RTGS_EINVAL;
+  hipLaunchKernelGGL(k_covariance, grid_for(n, 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     n, rotation, scale, cov6, cov_inv6);
+  return check_launch();
+}
+
+int rtgs_generate_rays(const RtgsCamera* cam, float* rays, rtgs_stream_t stream) {
+  if (!cam || !rays || cam->width <= 0 || cam->height <= 0 || !(cam->fx > 0.f) || !(cam->fy > 0.f))
+    return RTGS_EINVAL;
+  hipLaunchKernelGGL(k_generate_rays, grid_for((size_t)cam->width * cam->height, 256), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), *cam, rays);
+  return check_launch();
+}
+
+int rtgs_closest_hit(const RtgsScene* scene, int32_t n_rays, const float* rays, int32_t* hit_idx,
+                     float* hit_t, rtgs_stream_t stream) {
+  if (!scene || scene->n <= 0 || !scene->position || !scene->cov_inv6) return RTGS_EINVAL;
+  if (n_rays <= 0 || !rays || !hit_idx || !hit_t) return RTGS_EINVAL;
+  hipLaunchKernelGGL(k_closest_hit, grid_for(n_rays, kHitBlock), dim3(kHitBlock), 0,
+                     static_cast<hipStream_t>(stream), scene->n, scene->position, scene->cov_inv6,
+                     n_rays, rays, hit_idx, hit_t);
+  return check_launch();
+}
+
+int rtgs_gaussian_hit(int32_t n, const float* rays, const float* position, const float* cov_inv6,
+                      float* hit_t, rtgs_stream_t stream) {
+  if (n <= 0 || !rays || !position || !cov_inv6 || !hit_t) return RTGS_EINVAL;
+  hipLaunchKernelGGL(k_gaussian_hit, grid_for(n, 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     n, rays, position, cov_inv6, hit_t);
+  return check_launch();
+}
+
+int rtgs_gaussian_eval(int32_t n, const float* pos, const float* dir, const float* position,
+                       const float* cov_inv6, const float* color_opacity, const float* sh, float* out,
+                       rtgs_stream_t stream) {
+  if (n <= 0 || !pos || !dir || !position || !cov_inv6 || !color_opacity || !out) return RTGS_EINVAL;
+  hipLaunchKernelGGL(k_gaussian_eval, grid_for(n, 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     n, pos, dir, position, cov_inv6, color_opacity, sh, out);
+  return check_launch();
+}
+
+int rtgs_quat_op(int32_t op, int32_t n, const float* p, const float* q, float* out,
+                 rtgs_stream_t stream) {
+  if (op < 0 || op > 3 || n <= 0 || !p || !out) return RTGS_EINVAL;
+  if ((op == 0 || op == 2) && !q) return RTGS_EINVAL;
+  hipLaunchKernelGGL(k_quat_op, grid_for(n, 256), dim3(256), 0, static_cast<hipStream_t>(stream), op, n,
+                     p, q, out);
+  return check_launch();
+}
+
+int rtgs_ray_get(int32_t n, const float* rays, const float* t, float* out, rtgs_stream_t stream) {
+  if (n <= 0 || !rays || !t || !out) return RTGS_EINVAL;
+  hipLaunchKernelGGL(k_ray_get, grid_for(n, 256), dim3(256), 0, static_cast<hipStream_t>(stream), n,
+                     rays, t, out);
+  return check_launch();
+}
+
+int rtgs_disp_buffer(int32_t n_pixels, const float* sample_buf, int32_t num_samples, int32_t num_steps,
+                     int32_t num_depth, float* disp_buf, rtgs_stream_t stream) {
+  if (n_pixels <= 0 || !sample_buf || !disp_buf || num_depth <= 0) return RTGS_EINVAL;
+  // ray_tracer.py:76-77: num_samples + float(num_steps) / float(num_depth)
+  const float denom = (float)num_samples + (float)num_steps / (float)num_depth;
+  const size_t n = (size_t)n_pixels * 3;
+  hipLaunchKernelGGL(k_disp, grid_for(n, 256), dim3(256), 0, static_cast<hipStream_t>(stream), n,
+                     sample_buf, denom, disp_buf);
+  return check_launch();
+}
+
+int rtgs_fill(float* dst, size_t n, float value, rtgs_stream_t stream) {
+  if (!dst || n == 0) return RTGS_EINVAL;
+  hipLaunchKernelGGL(k_fill, grid_for(n, 256), dim3(256), 0, static_cast<hipStream_t>(stream), dst, n,
+                     value);
+  return check_launch();
+}
+
+}  // extern "C"

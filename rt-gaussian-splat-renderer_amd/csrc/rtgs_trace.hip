@@ -1,0 +1,549 @@
+// rtgs_trace.hip -- the hot path: per-frame projection + one-pass trace/sort/composite.
+//
+// Reference semantics (paths relative to the reference's src/rtgs/):
+//   ray generation        camera.py:31-71
+//   ray/ellipsoid quadratic  gaussian.py:203-230  (A, B, C, delta, t1, t2; threshold 3)
+//   closest-hit criteria  scene.py:433-437         (start < t1 < end, argmin t1)
+//   peel + composite      ray_tracer.py:39-54, 79-104
+//   shading               gaussian.py:140-201      (alpha = opacity*exp(-d^T S^-1 d), SH)
+//
+// MI355X design (not the reference's: it walks a BVH per ray per peel with fp32 3x3 inverses):
+//   * k_project (once per frame, one thread per Gaussian, fp64 inside): the quadratic of
+//     gaussian.py:215-219 is factored per Gaussian.  With E = (X, Y, -1), X/Y the pixel-centre
+//     offsets from the image centre, delta/4 = E^T Q E is a conic in the image plane.  For an
+//     ellipsoid in front of the camera it is an ellipse; it is stored CENTRED
+//         delta/4 = K - (p00 x^2 + 2 p01 x y + p11 y^2),  (x, y) = (X, Y) - centre
+//     with the centre split hi+lo so the fp32 per-ray evaluation has no cancellation (the
+//     literal b^2 - A*C loses ~1e-3 relative for a 0.01-unit Gaussian 3 units away).  A and
+//     b = B/2 are stored as Taylor polynomials about the same centre.  Gaussians that contain
+//     the camera or lie behind it are culled here (they can never satisfy t1 > 0); conics that
+//     are not clean ellipses (ellipsoid crossing the camera plane) keep the general form.
+//   * k_trace: one 1024-thread workgroup per 32x32 macro-tile, one wave64 per 8x8 pixel tile,
+//     one lane per ray.  The workgroup streams all screen bounds (16 B/Gaussian, SoA in HBM,
+//     L2-resident) in slabs; lanes test one Gaussian each against the macro-tile and compact
+//     survivors into an LDS list with wave ballots.  Each wave then re-tests the survivors
+//     against its own 8x8 tile (one survivor per lane, ballot), and for every set bit all 64
+//     rays evaluate the exact conic.  Hits go into a per-lane sorted register list of the
+//     `RTGS_MAX_DEPTH` nearest (t1, index) -- the reference's `depth` peels in one pass -- and
+//     are composited front to back at the end; a wave ballot ends the compositing loop early
+//     when every lane is below the transmittance cut-off.  No MFMA: there is no contraction.
+#include "rtgs_common.hpp"
+
+namespace rtgs {
+namespace {
+
+constexpr int kStreamIters = 4;                          // bounds loads in flight per thread
+constexpr int kSuper = kStreamIters * kTraceBlock;       // Gaussians streamed per barrier
+constexpr int kListCap = 2 * kSuper;                     // LDS survivor list (indices)
+
+struct TraceArgs {
+  int32_t n;
+  int32_t width, height;
+  int32_t tiles_x;
+  int32_t tile_first, tile_step;
+  int32_t depth;
+  float t_cutoff;
+  uint32_t flags;
+  float inv_fx, inv_fy;
+  float rc[9];  // camera rotation, for the SH direction only
+  const float4* __restrict__ bbox;
+  const float* __restrict__ rec;
+  const float4* __restrict__ colop;
+  const float* __restrict__ sh;
+  float* sample;
+  float* att;
+  float* start;
+  int32_t start_stride;
+};
+
+// ------------------------------------------------------------------------------------
+// per-frame projection
+// ------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_project(int32_t n, const float* __restrict__ pos,
+                                                  const float* __restrict__ ci6, FrameCam cam,
+                                                  float4* __restrict__ bbox,
+                                                  float* __restrict__ rec) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  const double inf = __builtin_huge_val();
+  float4 bb = make_float4(kInf, kInf, -kInf, -kInf);  // empty: culled
+  float r[kRecFloats];
+#pragma unroll
+  for (int k = 0; k < kRecFloats; ++k) r[k] = 0.f;
+
+  const double mx = cam.o[0] - (double)pos[3 * g + 0];
+  const double my = cam.o[1] - (double)pos[3 * g + 1];
+  const double mz = cam.o[2] - (double)pos[3 * g + 2];
+  const double Mxx = ci6[6 * g + 0], Mxy = ci6[6 * g + 1], Mxz = ci6[6 * g + 2];
+  const double Myy = ci6[6 * g + 3], Myz = ci6[6 * g + 4], Mzz = ci6[6 * g + 5];
+  // u = M m ; C = m.M m - 3   (gaussian.py:217-219)
+  const double u0 = Mxx * mx + Mxy * my + Mxz * mz;
+  const double u1 = Mxy * mx + Myy * my + Myz * mz;
+  const double u2 = Mxz * mx + Myz * my + Mzz * mz;
+  const double C = mx * u0 + my * u1 + mz * u2 - 3.0;
+
+  if (C > 0.0) {  // camera outside the ellipsoid (inside: t1 < 0 < t2, never a hit)
+    // camera frame, focal lengths folded in: D = diag(1/fx, 1/fy, 1) E, d_world = rc D.
+    const double sc[3] = {cam.inv_fx, cam.inv_fy, 1.0};
+    double col[3][3];  // col[k] = k-th column of rc scaled by sc[k]
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      col[k][0] = cam.rc[0 + k] * sc[k];
+      col[k][1] = cam.rc[3 + k] * sc[k];
+      col[k][2] = cam.rc[6 + k] * sc[k];
+    }
+    double v[3], Mc[3][3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      v[k] = col[k][0] * u0 + col[k][1] * u1 + col[k][2] * u2;
+      const double t0 = Mxx * col[k][0] + Mxy * col[k][1] + Mxz * col[k][2];
+      const double t1 = Mxy * col[k][0] + Myy * col[k][1] + Myz * col[k][2];
+      const double t2 = Mxz * col[k][0] + Myz * col[k][1] + Mzz * col[k][2];
+#pragma unroll
+      for (int l = 0; l < 3; ++l) Mc[l][k] = col[l][0] * t0 + col[l][1] * t1 + col[l][2] * t2;
+    }
+    // Q = v v^T - C Mc ; delta/4 = E^T Q E, E = (X, Y, -1)
+    const double Q00 = v[0] * v[0] - C * Mc[0][0];
+    const double Q01 = v[0] * v[1] - C * Mc[0][1];
+    const double Q11 = v[1] * v[1] - C * Mc[1][1];
+    const double Q02 = v[0] * v[2] - C * Mc[0][2];
+    const double Q12 = v[1] * v[2] - C * Mc[1][2];
+    const double Q22 = v[2] * v[2] - C * Mc[2][2];
+    const double det = Q00 * Q11 - Q01 * Q01;
+    bool general = true;
+    if (Q00 < 0.0 && det > 0.0) {  // ellipse
+      const double X0 = (Q11 * Q02 - Q01 * Q12) / det;
+      const double Y0 = (Q00 * Q12 - Q01 * Q02) / det;
+      const double K = Q22 - (Q02 * X0 + Q12 * Y0);
+      const double hx = sqrt(K * (-Q11) / det);
+      const double hy = sqrt(K * (-Q00) / det);
+      const double lim = 4.0e6;  // beyond this the hi/lo split is no longer exact
+      if (K > 0.0 && fabs(X0) < lim && fabs(Y0) < lim && hx < lim && hy < lim) {
+        general = false;
+        const double b0 = v[0] * X0 + v[1] * Y0 - v[2];
+        if (b0 < 0.0) {  // in front of the camera (b0 >= 0: the mirror cone, t1 < 0)
+          const double pad_x = 1e-3 + 1e-5 * (fabs(X0) + hx);
+          const double pad_y = 1e-3 + 1e-5 * (fabs(Y0) + hy);
+          bb = make_float4((float)(X0 - hx - pad_x), (float)(Y0 - hy - pad_y),
+                           (float)(X0 + hx + pad_x), (float)(Y0 + hy + pad_y));
+          const double xh = rint(2.0 * X0) * 0.5, yh = rint(2.0 * Y0) * 0.5;
+          const double e0 = Mc[0][0] * X0 + Mc[0][1] * Y0 - Mc[0][2];
+          const double e1 = Mc[1][0] * X0 + Mc[1][1] * Y0 - Mc[1][2];
+          const double e2 = Mc[2][0] * X0 + Mc[2][1] * Y0 - Mc[2][2];
+          r[0] = (float)xh;        r[1] = (float)yh;
+          r[2] = (float)(X0 - xh); r[3] = (float)(Y0 - yh);
+          r[4] = (float)(-Q00);    r[5] = (float)(-2.0 * Q01);
+          r[6] = (float)(-Q11);    r[7] = (float)K;
+          r[8] = (float)(X0 * e0 + Y0 * e1 - e2);  // A at the centre
+          r[9] = (float)(2.0 * e0); r[10] = (float)(2.0 * e1);
+          r[11] = (float)Mc[0][0]; r[12] = (float)(2.0 * Mc[0][1]);
+          r[13] = (float)Mc[1][1];
+          r[14] = (float)b0;       r[15] = (float)v[0];
+          r[16] = (float)v[1];     r[17] = __int_as_float(0);
+        }
+      } else if (!(K > 0.0)) {
+        general = false;  // negative-definite conic that never reaches 0: no pixel hits
+      }
+    }
+    if (general && C < inf) {
+      // Ellipsoid crossing the camera plane (or a degenerate conic): keep the quadratic of
+      // gaussian.py:215-219 in camera coordinates.  Such Gaussians are near the camera, where
+      // the direct form is well conditioned.  No screen bound.
+      bb = make_float4(-kInf, -kInf, kInf, kInf);
+      r[0] = (float)Mc[0][0];         r[1] = (float)(2.0 * Mc[0][1]);
+      r[2] = (float)(2.0 * Mc[0][2]); r[3] = (float)Mc[1][1];
+      r[4] = (float)(2.0 * Mc[1][2]); r[5] = (float)Mc[2][2];
+      r[6] = (float)v[0]; r[7] = (float)v[1]; r[8] = (float)v[2];
+      r[9] = (float)C;
+      r[17] = __int_as_float(1);
+    }
+  }
+  bbox[g] = bb;
+  float4* out = reinterpret_cast<float4*>(rec + (size_t)g * kRecFloats);
+#pragma unroll
+  for (int k = 0; k < kRecFloats / 4; ++k)
+    out[k] = make_float4(r[4 * k], r[4 * k + 1], r[4 * k + 2], r[4 * k + 3]);
+}
+
+// ------------------------------------------------------------------------------------
+// trace
+// ------------------------------------------------------------------------------------
+
+__device__ __forceinline__ float bcast(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// Sorted insert into the per-lane list of the RTGS_MAX_DEPTH smallest keys.  A key is
+// (t1 bits << 32 | Gaussian index): t1 > 0, so unsigned order == (t1, index) lexicographic
+// order, which makes the result independent of the order Gaussians arrive in.
+__device__ __forceinline__ void list_insert(unsigned long long (&key)[RTGS_MAX_DEPTH],
+                                            float (&wexp)[RTGS_MAX_DEPTH],
+                                            unsigned long long kn, float wn) {
+#pragma unroll
+  for (int k = 0; k < RTGS_MAX_DEPTH; ++k) {
+    const bool lt = kn < key[k];
+    const unsigned long long kk = key[k];
+    const float ww = wexp[k];
+    key[k] = lt ? kn : kk;
+    wexp[k] = lt ? wn : ww;
+    kn = lt ? kk : kn;
+    wn = lt ? ww : wn;
+  }
+}
+
+// gaussian.py:149-163, including the y_33 quirk (5 z^2 - 3 z).
+__device__ __forceinline__ void sh_basis(float x, float y, float z, float (&Y)[RTGS_SH_COEFFS]) {
+  constexpr float c0 = 0.97720502380583984f, c1 = 2.1850968611841584f, c2 = 1.2615662610100802f,
+                  c3 = 2.3601743597065673f, c4 = 5.7812228852811081f, c5 = 1.8281831978578629f,
+                  c6 = 1.4927053303604616f;
+  Y[0] = 0.5f * c0 * y;
+  Y[1] = 0.5f * c0 * z;
+  Y[2] = 0.5f * c0 * x;
+  Y[3] = 0.5f * c1 * x * y;
+  Y[4] = 0.5f * c1 * y * z;
+  Y[5] = 0.25f * c2 * (3.f * z * z - 1.f);
+  Y[6] = 0.5f * c1 * x * z;
+  Y[7] = 0.25f * c1 * (x * x - y * y);
+  Y[8] = 0.25f * c3 * y * (3.f * x * x - y * y);
+  Y[9] = 0.5f * c4 * x * y * z;
+  Y[10] = 0.25f * c5 * y * (5.f * z * z - 1.f);
+  Y[11] = 0.25f * c6 * (5.f * z * z - 3.f * z);
+  Y[12] = 0.25f * c5 * x * (5.f * z * z - 1.f);
+  Y[13] = 0.25f * c4 * (x * x - y * y) * z;
+  Y[14] = 0.25f * c3 * x * (x * x - 3.f * y * y);
+}
+
+template <bool kHasSh>
+__global__ __launch_bounds__(kTraceBlock) void k_trace(const TraceArgs a) {
+  __shared__ int s_idx[kListCap];
+  __shared__ int s_wcnt[2][kWavesPerTile];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wave = tid >> 6;
+  const int tile = a.tile_first + (int)blockIdx.x * a.tile_step;
+  const int mi0 = (tile % a.tiles_x) * kTile;
+  const int mj0 = (tile / a.tiles_x) * kTile;
+  const int wi0 = mi0 + (wave % kWavesX) * kWaveTile;
+  const int wj0 = mj0 + (wave / kWavesX) * kWaveTile;
+  const int pi = wi0 + (lane >> 3);
+  const int pj = wj0 + (lane & 7);
+  const bool in_img = pi < a.width && pj < a.height;
+  const bool wave_live = wi0 < a.width && wj0 < a.height;
+
+  const float hw = 0.5f * (float)a.width, hh = 0.5f * (float)a.height;
+  const float X = ((float)pi + 0.5f) - hw;   // exact: half-integers
+  const float Y = ((float)pj + 0.5f) - hh;
+  // bounds of pixel centres covered by the macro-tile and by this wave's tile
+  const float mXlo = ((float)mi0 + 0.5f) - hw;
+  const float mXhi = ((float)min(mi0 + kTile, a.width) - 0.5f) - hw;
+  const float mYlo = ((float)mj0 + 0.5f) - hh;
+  const float mYhi = ((float)min(mj0 + kTile, a.height) - 0.5f) - hh;
+  const float wXlo = ((float)wi0 + 0.5f) - hw;
+  const float wXhi = ((float)min(wi0 + kWaveTile, a.width) - 0.5f) - hw;
+  const float wYlo = ((float)wj0 + 0.5f) - hh;
+  const float wYhi = ((float)min(wj0 + kWaveTile, a.height) - 0.5f) - hh;
+
+  // |D| of this pixel's unnormalised camera-space direction D = (X/fx, Y/fy, -1): the
+  // reference's t is along normalize(D) (camera.py:49-50), ours along D.
+  const float dcx = X * a.inv_fx, dcy = Y * a.inv_fy;
+  const float dlen = sqrtf(dcx * dcx + dcy * dcy + 1.0f);
+
+  const size_t pix = (size_t)pi * a.height + pj;
+  float start = 0.f;
+  if ((a.flags & RTGS_TRACE_RESUME) && in_img) start = a.start[pix * a.start_stride];
+
+  unsigned long long key[RTGS_MAX_DEPTH];
+  float wexp[RTGS_MAX_DEPTH];
+  constexpr unsigned long long kEmpty = 0x7F800000FFFFFFFFull;  // (+inf, -1)
+#pragma unroll
+  for (int k = 0; k < RTGS_MAX_DEPTH; ++k) { key[k] = kEmpty; wexp[k] = 0.f; }
+
+  // Survivor list bookkeeping is deterministic and atomic-free: every wave publishes how many
+  // Gaussians of the super-slab it keeps, one barrier later every thread derives the same
+  // offsets and the same running count `cnt` (kept in a register, identical in all threads).
+  // s_wcnt is double-buffered by super-slab parity: waves are never more than one barrier apart.
+  int cnt = 0;
+  const unsigned long long lane_lt = (1ull << lane) - 1ull;
+
+  for (int base = 0, par = 0; base < a.n; base += kSuper, par ^= 1) {
+    // ---- stream one super-slab of screen bounds, keep what touches the macro-tile ----
+    float4 bb[kStreamIters];
+#pragma unroll
+    for (int it = 0; it < kStreamIters; ++it) {
+      const int g = base + it * kTraceBlock + tid;
+      bb[it] = make_float4(kInf, kInf, -kInf, -kInf);
+      if (g < a.n) bb[it] = a.bbox[g];
+    }
+    unsigned long long keep_m[kStreamIters];
+    int wcnt = 0;
+#pragma unroll
+    for (int it = 0; it < kStreamIters; ++it) {
+      const bool keep = bb[it].x <= mXhi && bb[it].z >= mXlo && bb[it].y <= mYhi && bb[it].w >= mYlo;
+      keep_m[it] = __ballot(keep);
+      wcnt += __popcll(keep_m[it]);
+    }
+    if (lane == 0) s_wcnt[par][wave] = wcnt;
+    __syncthreads();
+    int off = cnt;
+#pragma unroll
+    for (int w = 0; w < kWavesPerTile; ++w) {
+      const int c = s_wcnt[par][w];
+      off += (w < wave) ? c : 0;
+      cnt += c;
+    }
+#pragma unroll
+    for (int it = 0; it < kStreamIters; ++it) {
+      if ((keep_m[it] >> lane) & 1ull)
+        s_idx[off + __popcll(keep_m[it] & lane_lt)] = base + it * kTraceBlock + tid;
+      off += __popcll(keep_m[it]);
+    }
+    const bool last = base + kSuper >= a.n;
+    if (cnt + kSuper <= kListCap && !last) continue;
+    __syncthreads();  // the list is complete
+
+    // ---- every wave: survivors vs its own 8x8 tile, then exact per-ray tests ----
+    if (wave_live) {
+      for (int c = 0; c < cnt; c += kWave) {
+        const int slot = c + lane;
+        const int g = slot < cnt ? s_idx[slot] : -1;
+        float4 wb = make_float4(kInf, kInf, -kInf, -kInf);
+        if (g >= 0) wb = a.bbox[g];
+        const bool pass = wb.x <= wXhi && wb.z >= wXlo && wb.y <= wYhi && wb.w >= wYlo;
+        unsigned long long m = __ballot(pass);
+        if (!m) continue;
+        float4 r0, r1, r2, r3, r4;
+        r0 = r1 = r2 = r3 = r4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pass) {
+          const float4* rp = reinterpret_cast<const float4*>(a.rec + (size_t)g * kRecFloats);
+          r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = rp[3]; r4 = rp[4];
+        }
+        while (m) {
+          const int b = __builtin_ctzll(m);
+          m &= m - 1;
+          const int gi = __builtin_amdgcn_readlane(g, b);
+          const int type = __builtin_amdgcn_readlane(__float_as_int(r4.y), b);
+          float e, A, bq;
+          bool hit;
+          if (type == 0) {
+            const float x = (X - bcast(r0.x, b)) - bcast(r0.z, b);
+            const float y = (Y - bcast(r0.y, b)) - bcast(r0.w, b);
+            const float quad = (bcast(r1.x, b) * x + bcast(r1.y, b) * y) * x + (bcast(r1.z, b) * y) * y;
+            e = bcast(r1.w, b) - quad;                      // delta/4
+            hit = e > 0.f && in_img;
+            if (!__any(hit)) continue;
+            A = bcast(r2.x, b) + bcast(r2.y, b) * x + bcast(r2.z, b) * y +
+                (bcast(r2.w, b) * x + bcast(r3.x, b) * y) * x + (bcast(r3.y, b) * y) * y;
+            bq = bcast(r3.z, b) + bcast(r3.w, b) * x + bcast(r4.x, b) * y;
+          } else {
+            A = (bcast(r0.x, b) * X + bcast(r0.y, b) * Y - bcast(r0.z, b)) * X +
+                (bcast(r0.w, b) * Y - bcast(r1.x, b)) * Y + bcast(r1.y, b);
+            bq = bcast(r1.z, b) * X + bcast(r1.w, b) * Y - bcast(r2.x, b);
+            e = bq * bq - A * bcast(r2.y, b);
+            hit = e > 0.f && bq < 0.f && in_img;
+            if (!__any(hit)) continue;
+          }
+          const float rA = 1.0f / A;
+          const float t1 = ((-bq - sqrtf(e)) * rA) * dlen;   // gaussian.py:224
+          const bool cand = hit && t1 > start && t1 < kInf;  // scene.py:433
+          const unsigned long long kn =
+              cand ? (((unsigned long long)__float_as_uint(t1) << 32) | (unsigned)gi) : ~0ull;
+          if (__any(kn < key[RTGS_MAX_DEPTH - 1])) list_insert(key, wexp, kn, e * rA);
+        }
+      }
+    }
+    __syncthreads();  // everyone is done reading the list before it is refilled
+    cnt = 0;
+  }
+
+  // ---- front-to-back compositing of the sorted list (ray_tracer.py:88-104) ----
+  float T = 1.f;
+  if ((a.flags & RTGS_TRACE_RESUME) && in_img) T = a.att[pix];
+  float L0 = 0.f, L1 = 0.f, L2 = 0.f;
+  float Ysh[RTGS_SH_COEFFS];
+  if (kHasSh) {
+    const float il = 1.0f / dlen;
+    const float cx = dcx * il, cy = dcy * il, cz = -il;
+    float wx = a.rc[0] * cx + a.rc[1] * cy + a.rc[2] * cz;
+    float wy = a.rc[3] * cx + a.rc[4] * cy + a.rc[5] * cz;
+    float wz = a.rc[6] * cx + a.rc[7] * cy + a.rc[8] * cz;
+    const float in = 1.0f / sqrtf(wx * wx + wy * wy + wz * wz);  // gaussian.py:200
+    sh_basis(wx * in, wy * in, wz * in, Ysh);
+  }
+  int nhit = 0;
+  float last_t = 0.f;
+  unsigned prev_tbits = 0u;
+#pragma unroll
+  for (int k = 0; k < RTGS_MAX_DEPTH; ++k) {
+    if (k < a.depth) {
+      const unsigned tbits = (unsigned)(key[k] >> 32);
+      // an exact repeat of the previous entry distance is what the reference's strict
+      // `t1 > ray.start` drops (scene.py:433 after ray_tracer.py:101)
+      const bool valid = tbits < 0x7F800000u && tbits != prev_tbits;
+      const bool live = valid && !(a.t_cutoff > 0.f && T < a.t_cutoff);
+      if (a.t_cutoff > 0.f && !__any(live)) break;
+      prev_tbits = tbits;
+      const unsigned gi = (unsigned)(key[k] & 0xFFFFFFFFull);
+      float4 co = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (valid) co = a.colop[gi];
+      if (kHasSh) {
+        if (valid) {
+          const float* s = a.sh + (size_t)gi * (RTGS_SH_COEFFS * 3);
+#pragma unroll
+          for (int q = 0; q < RTGS_SH_COEFFS; ++q) {
+            co.x += Ysh[q] * s[3 * q + 0];
+            co.y += Ysh[q] * s[3 * q + 1];
+            co.z += Ysh[q] * s[3 * q + 2];
+          }
+        }
+      }
+      const float alpha = co.w * expf(wexp[k] - 3.0f);  // == exp(-d^T S^-1 d) at the chord midpoint
+      if (valid) {
+        const float wa = T * alpha;
+        L0 += wa * co.x; L1 += wa * co.y; L2 += wa * co.z;
+        T *= 1.0f - alpha;
+        last_t = __uint_as_float(tbits);
+        ++nhit;
+      }
+    }
+  }
+
+  if (a.flags & RTGS_TRACE_COMPACT) {
+    float* o = a.sample + ((size_t)blockIdx.x * kTile * kTile + (size_t)(pi - mi0) * kTile + (pj - mj0)) * 3;
+    o[0] = L0; o[1] = L1; o[2] = L2;
+  } else if (in_img) {
+    float* o = a.sample + pix * 3;
+    if (a.flags & RTGS_TRACE_ACCUMULATE) { L0 += o[0]; L1 += o[1]; L2 += o[2]; }
+    o[0] = L0; o[1] = L1; o[2] = L2;
+  }
+  if (in_img) {
+    if (a.att) a.att[pix] = T;
+    // ray_tracer.py:99-104: start = t1 + EPS after a hit, +inf after a miss
+    if (a.start) a.start[pix * a.start_stride] = (nhit == a.depth) ? last_t + 1e-8f : kInf;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_untile(const float* __restrict__ compact, int world,
+                                                 int tiles_per_rank, int width, int height,
+                                                 int tiles_x, float* __restrict__ image) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= width * height) return;
+  const int i = p / height, j = p % height;
+  const int tile = (j / kTile) * tiles_x + i / kTile;
+  const int rank = tile % world, local = tile / world;
+  const float* s = compact + (((size_t)rank * tiles_per_rank + local) * kTile * kTile +
+                              (size_t)(i % kTile) * kTile + (j % kTile)) * 3;
+  float* o = image + (size_t)p * 3;
+  o[0] = s[0]; o[1] = s[1]; o[2] = s[2];
+}
+
+inline int check_launch() { return hipGetLastError() == hipSuccess ? RTGS_OK : RTGS_ELAUNCH; }
+
+}  // namespace
+}  // namespace rtgs
+
+using namespace rtgs;
+
+extern "C" {
+
+size_t rtgs_workspace_bytes(int32_t n) {
+  if (n <= 0) return 0;
+  const size_t nn = ((size_t)n + 63) & ~(size_t)63;
+  return nn * sizeof(float4) + nn * kRecFloats * sizeof(float);
+}
+
+int32_t rtgs_num_tiles(int32_t width, int32_t height) {
+  if (width <= 0 || height <= 0) return 0;
+  return ((width + kTile - 1) / kTile) * ((height + kTile - 1) / kTile);
+}
+
+int32_t rtgs_num_local_tiles(int32_t width, int32_t height, int32_t tile_first, int32_t tile_step) {
+  const int32_t total = rtgs_num_tiles(width, height);
+  if (tile_step <= 0 || tile_first < 0 || tile_first >= total) return 0;
+  return (total - tile_first + tile_step - 1) / tile_step;
+}
+
+static int validate(const RtgsScene* scene, const RtgsCamera* cam, void* ws, size_t ws_bytes) {
+  if (!scene || !cam || !ws) return RTGS_EINVAL;
+  if (scene->n <= 0 || !scene->position || !scene->cov_inv6 || !scene->color_opacity) return RTGS_EINVAL;
+  if (cam->width <= 0 || cam->height <= 0 || !(cam->fx > 0.f) || !(cam->fy > 0.f)) return RTGS_EINVAL;
+  if (ws_bytes < rtgs_workspace_bytes(scene->n)) return RTGS_EWORKSPACE;
+  if (reinterpret_cast<uintptr_t>(ws) & 15u) return RTGS_EINVAL;
+  return RTGS_OK;
+}
+
+int rtgs_project(const RtgsScene* scene, const RtgsCamera* cam, void* workspace,
+                 size_t workspace_bytes, rtgs_stream_t stream) {
+  if (int rc = validate(scene, cam, workspace, workspace_bytes)) return rc;
+  const size_t nn = ((size_t)scene->n + 63) & ~(size_t)63;
+  float4* bbox = static_cast<float4*>(workspace);
+  float* rec = reinterpret_cast<float*>(bbox + nn);
+  const FrameCam fc = make_frame_cam(*cam);
+  const int block = 256;
+  hipLaunchKernelGGL(k_project, dim3((scene->n + block - 1) / block), dim3(block), 0,
+                     static_cast<hipStream_t>(stream), scene->n, scene->position, scene->cov_inv6,
+                     fc, bbox, rec);
+  return check_launch();
+}
+
+int rtgs_trace(const RtgsScene* scene, const RtgsCamera* cam, const RtgsTraceParams* params,
+               float* sample_buf, float* attenuation_buf, float* ray_start,
+               int32_t ray_start_stride, void* workspace, size_t workspace_bytes,
+               int32_t projected, rtgs_stream_t stream) {
+  if (!params || !sample_buf) return RTGS_EINVAL;
+  if (int rc = validate(scene, cam, workspace, workspace_bytes)) return rc;
+  if (params->depth < 1 || params->depth > RTGS_MAX_DEPTH) return RTGS_EDEPTH;
+  if (params->tile_step <= 0 || params->tile_first < 0 || !(params->t_cutoff >= 0.f)) return RTGS_EINVAL;
+  if ((params->flags & RTGS_TRACE_RESUME) && (!attenuation_buf || !ray_start)) return RTGS_EINVAL;
+  if (ray_start && ray_start_stride <= 0) return RTGS_EINVAL;
+  const int32_t local = rtgs_num_local_tiles(cam->width, cam->height, params->tile_first, params->tile_step);
+  if (local <= 0) return RTGS_OK;  // a shard with no tiles
+  if (!projected)
+    if (int rc = rtgs_project(scene, cam, workspace, workspace_bytes, stream)) return rc;
+
+  const size_t nn = ((size_t)scene->n + 63) & ~(size_t)63;
+  const FrameCam fc = make_frame_cam(*cam);
+  TraceArgs a;
+  a.n = scene->n;
+  a.width = cam->width;
+  a.height = cam->height;
+  a.tiles_x = (cam->width + kTile - 1) / kTile;
+  a.tile_first = params->tile_first;
+  a.tile_step = params->tile_step;
+  a.depth = params->depth;
+  a.t_cutoff = params->t_cutoff;
+  a.flags = params->flags;
+  a.inv_fx = (float)fc.inv_fx;
+  a.inv_fy = (float)fc.inv_fy;
+  for (int k = 0; k < 9; ++k) a.rc[k] = (float)fc.rc[k];
+  a.bbox = static_cast<const float4*>(workspace);
+  a.rec = reinterpret_cast<const float*>(a.bbox + nn);
+  a.colop = reinterpret_cast<const float4*>(scene->color_opacity);
+  a.sh = scene->sh;
+  a.sample = sample_buf;
+  a.att = attenuation_buf;
+  a.start = ray_start;
+  a.start_stride = ray_start ? ray_start_stride : 1;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (scene->sh)
+    hipLaunchKernelGGL(k_trace<true>, dim3(local), dim3(kTraceBlock), 0, s, a);
+  else
+    hipLaunchKernelGGL(k_trace<false>, dim3(local), dim3(kTraceBlock), 0, s, a);
+  return check_launch();
+}
+
+int rtgs_untile(const float* compact, int32_t world, int32_t tiles_per_rank, int32_t width,
+                int32_t height, float* image, rtgs_stream_t stream) {
+  if (!compact || !image || world <= 0 || tiles_per_rank <= 0 || width <= 0 || height <= 0) return RTGS_EINVAL;
+  const int32_t total = rtgs_num_tiles(width, height);
+  if ((int64_t)world * tiles_per_rank < total) return RTGS_EINVAL;
+  const int block = 256;
+  const int npx = width * height;
+  hipLaunchKernelGGL(k_untile, dim3((npx + block - 1) / block), dim3(block), 0,
+                     static_cast<hipStream_t>(stream), compact, world, tiles_per_rank, width, height,
+                     (width + kTile - 1) / kTile, image);
+  return check_launch();
+}
+
+}  // extern "C"

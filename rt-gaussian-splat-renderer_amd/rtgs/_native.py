@@ -1,0 +1,142 @@
+"""ctypes binding of the C ABI in include/rtgs_hip.h (librtgs_hip.so, hipcc --offload-arch=gfx950).
+
+There is deliberately no fallback: if the shared library is missing or a call fails, the caller
+gets an exception.  torch is imported first so that the library binds to the same libamdhip64
+(soname libamdhip64.so.7) that torch already loaded -- streams and device pointers are only
+meaningful inside one HIP runtime instance.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_size_t, c_uint32, c_void_p
+
+import torch  # noqa: F401  (must precede the CDLL load, see module docstring)
+
+ABI_VERSION = 1
+MAX_DEPTH = 16
+TILE = 32
+RAY_FLOATS = 8
+SH_COEFFS = 15
+
+TRACE_RESUME = 1
+TRACE_ACCUMULATE = 2
+TRACE_COMPACT = 4
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "librtgs_hip.so")
+
+
+class RtgsScene(Structure):
+    _fields_ = [("n", c_int32), ("position", c_void_p), ("cov_inv6", c_void_p),
+                ("color_opacity", c_void_p), ("sh", c_void_p)]
+
+
+class RtgsCamera(Structure):
+    _fields_ = [("position", c_float * 3), ("rotation", c_float * 4), ("width", c_int32),
+                ("height", c_int32), ("fx", c_float), ("fy", c_float)]
+
+
+class RtgsTraceParams(Structure):
+    _fields_ = [("depth", c_int32), ("t_cutoff", c_float), ("tile_first", c_int32),
+                ("tile_step", c_int32), ("flags", c_uint32)]
+
+
+# name -> (restype, argtypes); mirrors include/rtgs_hip.h one to one.
+PROTOTYPES = {
+    "rtgs_abi_version": (c_int32, []),
+    "rtgs_strerror": (c_char_p, [c_int32]),
+    "rtgs_covariance": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rtgs_generate_rays": (c_int32, [POINTER(RtgsCamera), c_void_p, c_void_p]),
+    "rtgs_workspace_bytes": (c_size_t, [c_int32]),
+    "rtgs_num_tiles": (c_int32, [c_int32, c_int32]),
+    "rtgs_num_local_tiles": (c_int32, [c_int32, c_int32, c_int32, c_int32]),
+    "rtgs_trace": (c_int32, [POINTER(RtgsScene), POINTER(RtgsCamera), POINTER(RtgsTraceParams),
+                             c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_int32,
+                             c_void_p]),
+    "rtgs_project": (c_int32, [POINTER(RtgsScene), POINTER(RtgsCamera), c_void_p, c_size_t,
+                               c_void_p]),
+    "rtgs_untile": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "rtgs_closest_hit": (c_int32, [POINTER(RtgsScene), c_int32, c_void_p, c_void_p, c_void_p,
+                                   c_void_p]),
+    "rtgs_gaussian_hit": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rtgs_gaussian_eval": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p]),
+    "rtgs_quat_op": (c_int32, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rtgs_ray_get": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rtgs_disp_buffer": (c_int32, [c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p,
+                                   c_void_p]),
+    "rtgs_fill": (c_int32, [c_void_p, c_size_t, c_float, c_void_p]),
+}
+
+_lib = None
+
+
+class RtgsError(RuntimeError):
+    """A negative return code from the C ABI."""
+
+
+def lib() -> ctypes.CDLL:
+    """Load librtgs_hip.so (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python __graft_entry__.py build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in PROTOTYPES.items():
+            fn = getattr(handle, name)  # AttributeError = missing export
+            fn.restype = restype
+            fn.argtypes = argtypes
+        got = handle.rtgs_abi_version()
+        if got != ABI_VERSION:
+            raise RuntimeError(f"librtgs_hip.so ABI {got} != binding ABI {ABI_VERSION}")
+        _lib = handle
+    return _lib
+
+
+def check(code: int, what: str = "rtgs") -> None:
+    """Map the ABI's integer error convention onto Python exceptions."""
+    if code == 0:
+        return
+    msg = lib().rtgs_strerror(code).decode()
+    if code in (-1, -2, -3):
+        raise ValueError(f"{what}: {msg} (code {code})")
+    raise RtgsError(f"{what}: {msg} (code {code})")
+
+
+def require_device(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name} must be a torch tensor on the HIP device (got "
+                           f"{type(t).__name__} on {getattr(t, 'device', '?')}); "
+                           "this path has no CPU implementation")
+    if t.dtype not in (torch.float32, torch.int32) or not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous float32/int32")
+    return t
+
+
+def ptr(t) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+def stream() -> int:
+    """The hipStream_t of torch's current stream, as the void* the ABI takes."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def device() -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError("no HIP device visible to torch; the rtgs render path needs an MI355X")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def make_camera(position, rotation, width, height, fx, fy) -> RtgsCamera:
+    c = RtgsCamera()
+    for k in range(3):
+        c.position[k] = float(position[k])
+    for k in range(4):
+        c.rotation[k] = float(rotation[k])
+    c.width, c.height = int(width), int(height)
+    c.fx, c.fy = float(fx), float(fy)
+    return c

@@ -1,0 +1,203 @@
+"""Gaussian-splat scene -- host mirror of the reference's src/rtgs/scene.py.
+
+The reference's ``Scene`` owns an AoS Gaussian field plus a binned-SAH BVH that accelerates
+``Scene.hit`` (scene.py:162-450).  Here the scene owns structure-of-arrays device buffers
+(position, inverse covariance, colour+opacity, optional SH) that the HIP kernels stream; the
+closest-hit *result* of ``Scene.hit`` (scene.py:433-437) is kept, the BVH is not built
+(SURVEY.md 8(f) #3): per-frame screen-space culling replaces it on the render path.
+"""
+
+from __future__ import annotations
+
+import logging
+import pathlib
+
+import numpy as np
+import torch
+
+from . import _native as nat
+from .gaussian import GaussianField
+from .ray import Ray, RayField
+from .utils.math import sigmoid
+from .utils.types import vec2
+
+logger = logging.getLogger(__name__)
+
+_PLY_TYPES = {"char": "i1", "int8": "i1", "uchar": "u1", "uint8": "u1", "short": "i2",
+              "int16": "i2", "ushort": "u2", "uint16": "u2", "int": "i4", "int32": "i4",
+              "uint": "u4", "uint32": "u4", "float": "f4", "float32": "f4", "double": "f8",
+              "float64": "f8"}
+
+
+class SceneHit:
+    """scene.py:24-33.  gaussian_idx == -1 means miss; depth is the reference's BVH leaf depth
+    (debug only) and is always 0 here."""
+
+    __slots__ = ("gaussian_idx", "intersections", "depth")
+
+    def __init__(self, gaussian_idx=-1, intersections=(np.inf, np.inf), depth=0):
+        self.gaussian_idx = int(gaussian_idx)
+        self.intersections = vec2(intersections)
+        self.depth = int(depth)
+
+    def __repr__(self):
+        return f"SceneHit(gaussian_idx={self.gaussian_idx}, intersections={self.intersections.tolist()})"
+
+
+def read_ply(path) -> dict:
+    """Vertex element of an ASCII/binary-little-endian PLY as {property: ndarray}."""
+    data = pathlib.Path(path).read_bytes()
+    marker = b"end_header\n"
+    end = data.find(marker)
+    if not data.startswith(b"ply") or end < 0:
+        raise ValueError(f"{path}: not a PLY file")
+    lines = data[:end].decode("ascii").splitlines()
+    fmt = next((ln.split()[1] for ln in lines if ln.startswith("format")), None)
+    n, props, in_vertex = 0, [], False
+    for ln in lines:
+        tok = ln.split()
+        if not tok:
+            continue
+        if tok[0] == "element":
+            in_vertex = tok[1] == "vertex"
+            if in_vertex:
+                n = int(tok[2])
+        elif tok[0] == "property" and in_vertex:
+            if tok[1] == "list":
+                raise ValueError(f"{path}: list properties on vertices are not supported")
+            props.append((tok[2], _PLY_TYPES[tok[1]]))
+    body = data[end + len(marker):]
+    if fmt == "binary_little_endian":
+        dt = np.dtype([(name, "<" + t) for name, t in props])
+        arr = np.frombuffer(body, dtype=dt, count=n)
+        return {name: np.ascontiguousarray(arr[name]) for name, _ in props}
+    if fmt == "ascii":
+        arr = np.loadtxt(body.decode("ascii").splitlines()[:n], dtype=np.float64, ndmin=2)
+        return {name: arr[:, k].astype(t) for k, (name, t) in enumerate(props)}
+    raise ValueError(f"{path}: unsupported PLY format {fmt}")
+
+
+class Scene:
+    """scene.py:64-87.  max_num_node / balance_weight / leaf_prim are accepted for signature
+    compatibility; they parameterise the reference's BVH, which this path does not build."""
+
+    def __init__(self, max_num_node: int = 128, balance_weight: int = 1, leaf_prim=8) -> None:
+        self.max_num_node = max_num_node
+        self.balance_weight = balance_weight
+        self.leaf_prim = leaf_prim
+        self.bvh_field = None
+        self.gaussian_field = None  # scene.py:83 allocates a shape-() field; filled by load
+        self.num_gaussians = 0
+        self.position = self.cov_inv6 = self.color_opacity = self.sh = None
+
+    # ---- construction ------------------------------------------------------------------
+    @classmethod
+    def from_arrays(cls, position, rotation, scale, color, opacity, sh=None, **kw) -> "Scene":
+        """Bulk constructor: post-activation values, exactly what ``Gaussian.init`` takes
+        (gaussian.py:59-84).  rotation is a unit quaternion xyzw; sh is (N, 15, 3) or None."""
+        scene = cls(**kw)
+        scene.set_arrays(position, rotation, scale, color, opacity, sh)
+        return scene
+
+    def set_arrays(self, position, rotation, scale, color, opacity, sh=None) -> None:
+        dev = nat.device()
+
+        def up(x, cols):
+            a = np.ascontiguousarray(np.asarray(x, dtype=np.float32)).reshape((-1,) + cols)
+            return torch.from_numpy(a).to(dev)
+
+        field = GaussianField(up(position, (3,)).shape[0], device=dev)
+        field.position, field.rotation = up(position, (3,)), up(rotation, (4,))
+        field.scale, field.color = up(scale, (3,)), up(color, (3,))
+        field.opacity = up(opacity, ())
+        n = field.position.shape[0]
+        for name, t in (("rotation", field.rotation), ("scale", field.scale),
+                        ("color", field.color), ("opacity", field.opacity)):
+            if t.shape[0] != n:
+                raise ValueError(f"{name} has {t.shape[0]} rows, position has {n}")
+        has_sh = sh is not None
+        field.sh = up(sh, (15, 3)) if has_sh else torch.zeros((n, 15, 3), dtype=torch.float32, device=dev)
+        field.n, field.shape = n, (n,)
+        self.gaussian_field = field
+        self.commit(has_sh)
+
+    def commit(self, has_sh: bool | None = None) -> None:
+        """(Re)build the device buffers the kernels stream from ``gaussian_field``:
+        quaternion+scale -> inverse covariance (gaussian.py:86-102 via ``rtgs_covariance``),
+        colour and opacity packed to 16 B."""
+        f = self.gaussian_field
+        n = f.n
+        if n <= 0:
+            raise ValueError("scene has no Gaussians")
+        self.num_gaussians = n
+        self.position = f.position.contiguous()
+        self.cov_inv6 = torch.empty((n, 6), dtype=torch.float32, device=f.position.device)
+        nat.check(nat.lib().rtgs_covariance(n, nat.ptr(f.rotation.contiguous()),
+                                            nat.ptr(f.scale.contiguous()), None,
+                                            nat.ptr(self.cov_inv6), nat.stream()), "rtgs_covariance")
+        self.color_opacity = torch.cat([f.color, f.opacity[:, None]], dim=1).contiguous()
+        if has_sh is None:
+            has_sh = bool(torch.any(f.sh != 0).item())
+        self.sh = f.sh.reshape(n, 45).contiguous() if has_sh else None
+
+    def load_file(self, path: pathlib.Path, scale: float = 1):
+        """Load an INRIA-3DGS PLY (scene.py:89-131): wxyz -> xyzw (:103), normalised
+        quaternions (:110-111), exp(scale) * scale (:112), sigmoid colour and opacity
+        (:113-114), f_rest reshaped (-1, 3, 15) (:106-107).
+
+        The kernel-side contract of the reference (scene.py:143-157) is that coefficient k of
+        Gaussian i is an RGB triple; the channel-major (3, 15) block is therefore transposed to
+        (15, 3) here (SURVEY.md 8c-i records that Taichi's own ingest cannot be checked)."""
+        p = read_ply(pathlib.Path(path))
+        num_points = len(p["x"])
+        logger.info(f"Point cloud loaded from {path} with {num_points} points.")
+        f32 = np.float32
+        positions = np.stack([p["x"], p["y"], p["z"]], axis=-1).astype(f32)
+        rotations = np.stack([p["rot_1"], p["rot_2"], p["rot_3"], p["rot_0"]], axis=-1).astype(f32)
+        scales = np.stack([p["scale_0"], p["scale_1"], p["scale_2"]], axis=-1).astype(f32)
+        colors = np.stack([p["f_dc_0"], p["f_dc_1"], p["f_dc_2"]], axis=-1).astype(f32)
+        sh = None
+        if all(f"f_rest_{i}" in p for i in range(45)):
+            sh = np.stack([p[f"f_rest_{i}"] for i in range(45)], axis=-1).astype(f32)
+            sh = np.ascontiguousarray(sh.reshape(-1, 3, 15).transpose(0, 2, 1))
+        opacities = p["opacity"].astype(f32)
+        rotations = rotations / np.linalg.norm(rotations, axis=-1)[:, np.newaxis]
+        scales = (np.exp(scales) * f32(scale)).astype(f32)
+        colors = sigmoid(colors)
+        opacities = sigmoid(opacities)
+        self.set_arrays(positions, rotations, scales, colors, opacities, sh)
+        logger.info("Gaussian field built.")
+
+    # ---- queries -----------------------------------------------------------------------
+    def native(self) -> nat.RtgsScene:
+        if self.position is None:
+            raise RuntimeError("scene is empty: call load_file() or set_arrays() first")
+        s = nat.RtgsScene()
+        s.n = self.num_gaussians
+        s.position = nat.ptr(self.position)
+        s.cov_inv6 = nat.ptr(self.cov_inv6)
+        s.color_opacity = nat.ptr(self.color_opacity)
+        s.sh = nat.ptr(self.sh)
+        return s
+
+    def hit_batch(self, rays):
+        """Closest hit of every ray of a ``RayField`` / (..., 8) device tensor
+        (scene.py:406-450).  Returns (gaussian_idx int32 (...), intersections float32 (..., 2))."""
+        data = rays.data if isinstance(rays, RayField) else rays
+        data = nat.require_device(data, "rays")
+        shape = data.shape[:-1]
+        n = data.numel() // nat.RAY_FLOATS
+        idx = torch.empty(shape, dtype=torch.int32, device=data.device)
+        t = torch.empty(shape + (2,), dtype=torch.float32, device=data.device)
+        if n:
+            scene = self.native()
+            nat.check(nat.lib().rtgs_closest_hit(scene, n, nat.ptr(data), nat.ptr(idx), nat.ptr(t),
+                                                 nat.stream()), "rtgs_closest_hit")
+        return idx, t
+
+    def hit(self, ray: Ray) -> SceneHit:
+        """Ray cast against the scene: the Gaussian with the smallest entry distance t1 with
+        ray.start < t1 < ray.end (scene.py:433-437)."""
+        data = torch.from_numpy(ray.as_array()[None, :]).to(nat.device())
+        idx, t = self.hit_batch(data)
+        return SceneHit(int(idx[0]), t[0].cpu().numpy(), 0)

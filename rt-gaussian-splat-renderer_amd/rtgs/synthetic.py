@@ -1,0 +1,84 @@
+"""Seeded synthetic random-Gaussian scenes and the benchmark camera.
+
+Host-side NumPy only (scene construction, like the reference's loader scene.py:95-114 is host
+NumPy code).  The five BASELINE.json configurations are named c1..c5.
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import numpy as np
+
+
+@dataclass(frozen=True)
+class Config:
+    name: str
+    n: int
+    width: int
+    height: int
+    seed: int
+    sh: bool = False
+    depth: int = 16
+
+    @property
+    def aspect(self) -> float:
+        return self.width / self.height
+
+    @property
+    def rays(self) -> int:
+        return self.width * self.height
+
+
+CONFIGS = {
+    "c1": Config("c1", 256, 128, 128, 1001),
+    "c2": Config("c2", 10_000, 800, 600, 1002),
+    "c3": Config("c3", 100_000, 1920, 1080, 1003),
+    "c4": Config("c4", 100_000, 1920, 1080, 1003),       # c3 sharded over 8 GPUs
+    "c5": Config("c5", 1_000_000, 3840, 2160, 1005, sh=True),
+}
+
+
+def bytes_per_ray(n: int, sh: bool = False, depth: int = 16) -> int:
+    """ALGORITHMIC bytes per ray fixed by SURVEY.md 8(d): every 64-pixel wave tile streams
+    every Gaussian's 36-B geometry, shading data for `depth` hits, one framebuffer write."""
+    return 36 * n // 64 + depth * 16 + (depth * 180 if sh else 0) + 12
+
+
+def make_scene(n: int, aspect: float, seed: int, sh: bool = False) -> dict:
+    """Random Gaussians in the box [-aspect, aspect] x [-1, 1] x [-1, 1].
+
+    Only rng.random() is used, in this fixed order: position (n,3), quaternion uniforms (n,3),
+    scale exponents (n,3), color (n,3), opacity (n), [sh (n,15,3)].  Everything is cast to fp32.
+    """
+    rng = np.random.default_rng(seed)
+    pos = rng.random((n, 3)) * 2.0 - 1.0
+    pos[:, 0] *= aspect
+    u = rng.random((n, 3))
+    # Shoemake: uniform unit quaternion from three uniforms, stored scalar-last (x, y, z, w)
+    a, b = np.sqrt(1.0 - u[:, 0]), np.sqrt(u[:, 0])
+    t1, t2 = 2.0 * math.pi * u[:, 1], 2.0 * math.pi * u[:, 2]
+    rot = np.stack([a * np.sin(t1), a * np.cos(t1), b * np.sin(t2), b * np.cos(t2)], axis=-1)
+    s0 = math.sqrt(8.727 * aspect / n)
+    scale = s0 * np.exp2(rng.random((n, 3)) * 2.0 - 1.0)
+    color = rng.random((n, 3))
+    opacity = 0.1 + 0.8 * rng.random(n)
+    out = dict(position=pos, rotation=rot, scale=scale, color=color, opacity=opacity, sh=None)
+    if sh:
+        out["sh"] = rng.random((n, 15, 3)) * 0.1 - 0.05
+    return {k: (None if v is None else np.ascontiguousarray(v, dtype=np.float32))
+            for k, v in out.items()}
+
+
+def make_config_scene(cfg: Config | str) -> dict:
+    if isinstance(cfg, str):
+        cfg = CONFIGS[cfg]
+    return make_scene(cfg.n, cfg.aspect, cfg.seed, cfg.sh)
+
+
+def bench_camera(width: int, height: int) -> dict:
+    """Camera of SURVEY.md 8(d): at (0,0,3) looking down -z, +y up, focal = H pixels (vertical
+    fov 53.13 deg), so the box's front face z = +1 exactly fills the frame."""
+    return dict(position=(0.0, 0.0, 3.0), rotation=(0.0, 0.0, 0.0, 1.0), width=width,
+                height=height, fx=float(height), fy=float(height))
