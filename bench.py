@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""Benchmark of the ray-traced Gaussian-splat render path (BASELINE.json metric: Mrays/s at
+1920x1080, 100k Gaussians; achieved HBM GB/s vs peak).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3]
+
+A step = one full frame of the hot path: per-frame projection + trace/sort/composite of every
+pixel (depth 16) and, for N > 1, the RCCL gather of the tile shards and the de-interleave on
+rank 0.  Scene and framebuffers are resident in HBM when the timed region starts.  One JSON
+line is printed by rank 0.  For N > 1 launch with torch.distributed.run (one rank per GPU).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "rt-gaussian-splat-renderer_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="c3", help="c2 | c3 | c5 (SURVEY.md 8d)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rays", type=int, default=256, help="rays of the NumPy baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, arrays, cam, n_rays):
+    """The oracle (NumPy, fp32, the reference's literal loop: `depth` closest-hit peels) timed
+    on this host, on a seeded pixel subset of the same workload.  Reported only."""
+    from oracle import rtgs_ref as ref
+
+    rng = np.random.default_rng(4242)
+    pix = np.stack([rng.integers(0, cfg.width, n_rays), rng.integers(0, cfg.height, n_rays)], axis=-1)
+    osc = ref.OracleScene(**arrays, dtype=np.float32)
+    t0 = time.perf_counter()
+    ref.render_peel(osc, cam["position"], cam["rotation"], cfg.width, cfg.height, cam["fx"],
+                    cam["fy"], depth=cfg.depth, pixels=pix)
+    dt = time.perf_counter() - t0
+    out = {"value": n_rays / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
+           "sample": f"{n_rays} seeded random pixels of the {cfg.name} frame, NumPy fp32 literal "
+                     f"depth-{cfg.depth} peel loop, {dt:.1f} s, 1 of {os.cpu_count()} cores "
+                     "(subset extrapolation)"}
+    # optional second line: the C/OpenMP restatement on all cores
+    try:
+        from oracle import c_oracle
+        if c_oracle.available():
+            n2 = min(cfg.rays, 16384)
+            pix2 = np.stack([rng.integers(0, cfg.width, n2), rng.integers(0, cfg.height, n2)], axis=-1)
+            t0 = time.perf_counter()
+            c_oracle.render(arrays, cam, cfg.depth, pix2)
+            dt2 = time.perf_counter() - t0
+            out["c_openmp"] = {"value": n2 / dt2 / 1e6, "unit": "Mrays/s", "cores": os.cpu_count(),
+                               "sample": f"{n2} seeded random pixels, C fp64 one-pass, {dt2:.1f} s"}
+    except Exception as exc:  # the optional line must never break the bench
+        out["c_openmp"] = {"error": repr(exc)}
+    return out
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run "
+                             "(--nproc-per-node N)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import rtgs
+    from rtgs import _native as nat
+    from rtgs import synthetic
+    from rtgs.parallel import TileParallelRenderer
+
+    cfg = synthetic.CONFIGS[args.config]
+    arrays = synthetic.make_config_scene(cfg)
+    cam = synthetic.bench_camera(cfg.width, cfg.height)
+    scene = rtgs.Scene.from_arrays(**arrays)
+    camera = rtgs.Camera(cam["position"], cam["rotation"], (cfg.width, cfg.height), (cam["fx"], cam["fy"]))
+    renderer = TileParallelRenderer(scene, camera, depth=cfg.depth, rank=rank, world=world)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        renderer.render_frame()
+    renderer.finish()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        renderer.render_frame()
+    renderer.finish()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant kernel (k_trace) alone, HIP events on the launch stream, projection already done
+    reps = max(10, min(args.steps, 100))
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    renderer.trace_only()
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(reps):
+        renderer.trace_only()
+    ev1.record()
+    torch.cuda.synchronize()
+    trace_ms = ev0.elapsed_time(ev1) / reps
+    ev0.record()
+    for _ in range(reps):
+        renderer.project_only()
+    ev1.record()
+    torch.cuda.synchronize()
+    project_ms = ev0.elapsed_time(ev1) / reps
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        mrays = cfg.rays / (elapsed / args.steps) / 1e6
+        bpr = synthetic.bytes_per_ray(cfg.n, cfg.sh, cfg.depth)
+        local_rays = renderer.local_tiles * nat.TILE * nat.TILE
+        achieved = bpr * min(local_rays, cfg.rays) / (trace_ms * 1e-3) / 1e9  # GB/s, this rank's launch
+        line = {
+            "metric": "Mrays/s at 1920x1080, 100k Gaussians; achieved HBM GB/s vs peak",
+            "value": mrays, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{cfg.name}: {cfg.n} random Gaussians (seed {cfg.seed}), "
+                                   f"{cfg.width}x{cfg.height}, depth {cfg.depth}, "
+                                   f"{'SH deg 3' if cfg.sh else 'no SH'}, camera (0,0,3) f=H",
+                       "rays_per_frame": cfg.rays, "gaussians": cfg.n,
+                       "parallelism": f"tile-parallel x{world}" + (" + RCCL gather" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "kernel": "k_trace", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel_ms": trace_ms, "project_ms": project_ms,
+                         "algorithmic_bytes_per_ray": bpr,
+                         "note": "achieved = SURVEY 8(d) streamed bytes/ray x rays per launch / "
+                                 "k_trace time; screen-space culling skips most of that stream, "
+                                 "so frac > 1 is possible; physical HBM bytes: profiles/"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, arrays, cam, args.cpu_rays)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -477,11 +477,15 @@ def render_topk(scene, cam_position, cam_rotation, width, height, fx, fy, depth=
     ray_sh = None
     if scene.sh is not None:
         ray_sh = sh_basis(dirs / np.sqrt(np.sum(dirs * dirs, axis=-1, keepdims=True)), dt)
-    for k in range(depth):
-        valid = np.isfinite(keep_t[:, k])
+    prev_t = np.full(n, -1.0, dtype=dt)
+    for k in range(K):
+        # an exact repeat of the previous entry distance is dropped: the reference's strict
+        # `t1 > ray.start` (scene.py:433) cannot see it after ray_tracer.py:101
+        valid = np.isfinite(keep_t[:, k]) & (keep_t[:, k] != prev_t) & (hits < depth)
+        prev_t = np.where(np.isfinite(keep_t[:, k]), keep_t[:, k], prev_t)
         h = np.nonzero(valid)[0]
         if h.size == 0:
-            break
+            continue
         gi = keep_i[h, k]
         alpha = scene.opacity[gi] * np.exp(keep_w[h, k] - dt(BOUNDING_THRESHOLD))
         rgb = scene.color[gi]

@@ -1,0 +1,128 @@
+"""Tile-parallel rendering: one process per GPU, macro-tiles interleaved over ranks, RCCL gather.
+
+The reference is single-process / single-device (no collective anywhere).  Pixels
+are independent, so the frame shards naturally: the 32x32 macro-tiles are dealt round-robin
+(tile t -> rank t % world), every rank holds the whole scene (one broadcast at load, Gaussians
+are replicated) and renders its tiles into a compact [tiles_per_rank, 32, 32, 3] buffer, and ONE
+exchange step -- a ``torch.distributed`` gather (backend "nccl" == RCCL over xGMI) of
+W*H*12/world bytes per rank -- lands the shards on the destination rank, where ``rtgs_untile``
+de-interleaves them into the (W, H, 3) framebuffer.  Frames are double-buffered: the gather of
+frame f overlaps the trace of frame f+1 on the ranks that are not the destination.
+"""
+
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def tiles_of(width: int, height: int, tile: int = 32) -> int:
+    return ((width + tile - 1) // tile) * ((height + tile - 1) // tile)
+
+
+def local_tile_count(total: int, rank: int, world: int) -> int:
+    """Tiles rank owns under the round-robin deal (== rtgs_num_local_tiles)."""
+    return 0 if rank >= total else (total - rank + world - 1) // world
+
+
+class HipBackend:
+    """The product backend: HIP kernels through the C ABI (include/rtgs_hip.h)."""
+
+    def __init__(self, scene, camera, depth: int, t_cutoff: float = 0.0):
+        from . import _native as nat
+        self.nat = nat
+        self.scene, self.camera = scene, camera
+        self.depth, self.t_cutoff = int(depth), float(t_cutoff)
+        self.device = nat.device()
+        self.width, self.height = camera.buf_size.x, camera.buf_size.y
+        need = nat.lib().rtgs_workspace_bytes(scene.num_gaussians)
+        self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+
+    def alloc(self, *shape):
+        return torch.zeros(shape, dtype=torch.float32, device=self.device)
+
+    def project(self):
+        nat = self.nat
+        nat.check(nat.lib().rtgs_project(self.scene.native(), self.camera.native(),
+                                         nat.ptr(self.workspace), self.workspace.numel(),
+                                         nat.stream()), "rtgs_project")
+
+    def trace(self, out, tile_first: int, tile_step: int, compact: bool, projected: bool = False):
+        nat = self.nat
+        params = nat.RtgsTraceParams(self.depth, self.t_cutoff, tile_first, tile_step,
+                                     nat.TRACE_COMPACT if compact else 0)
+        nat.check(nat.lib().rtgs_trace(self.scene.native(), self.camera.native(), params,
+                                       nat.ptr(out), None, None, 1, nat.ptr(self.workspace),
+                                       self.workspace.numel(), 1 if projected else 0, nat.stream()),
+                  "rtgs_trace")
+
+    def untile(self, gathered, world: int, tiles_per_rank: int, image):
+        nat = self.nat
+        nat.check(nat.lib().rtgs_untile(nat.ptr(gathered), world, tiles_per_rank, self.width,
+                                        self.height, nat.ptr(image), nat.stream()), "rtgs_untile")
+
+
+class TileParallelRenderer:
+    """Renders whole frames on `world` ranks; the image lands in ``framebuffer`` on rank `dst`."""
+
+    TILE = 32
+
+    def __init__(self, scene=None, camera=None, depth: int = 16, rank: int = 0, world: int = 1,
+                 t_cutoff: float = 0.0, dst: int = 0, group=None, backend=None):
+        self.backend = backend if backend is not None else HipBackend(scene, camera, depth, t_cutoff)
+        self.rank, self.world, self.dst, self.group = int(rank), int(world), int(dst), group
+        b = self.backend
+        self.total_tiles = tiles_of(b.width, b.height, self.TILE)
+        self.tiles_per_rank = (self.total_tiles + self.world - 1) // self.world
+        self.local_tiles = local_tile_count(self.total_tiles, self.rank, self.world)
+        self.framebuffer = b.alloc(b.width, b.height, 3) if (self.world == 1 or self.rank == self.dst) else None
+        self._pending = None
+        self._frame = 0
+        if self.world > 1:
+            shard = (self.tiles_per_rank, self.TILE, self.TILE, 3)
+            self.compact = [b.alloc(*shard), b.alloc(*shard)]
+            self.gathered = ([b.alloc(self.world, *shard), b.alloc(self.world, *shard)]
+                             if self.rank == self.dst else [None, None])
+
+    # ---- frame loop ------------------------------------------------------------------------
+    def render_frame(self) -> None:
+        """Queue one frame.  world == 1: straight into ``framebuffer``.  world > 1: trace this
+        rank's tiles, start the gather, then complete the previous frame (double buffering)."""
+        b = self.backend
+        if self.world == 1:
+            b.trace(self.framebuffer, 0, 1, compact=False)
+            return
+        k = self._frame & 1
+        self._frame += 1
+        if self.local_tiles:
+            b.trace(self.compact[k], self.rank, self.world, compact=True)
+        glist = list(self.gathered[k].unbind(0)) if self.rank == self.dst else None
+        work = dist.gather(self.compact[k], gather_list=glist, dst=self.dst, group=self.group,
+                           async_op=True)
+        prev, self._pending = self._pending, (work, k)
+        self._complete(prev)
+
+    def _complete(self, pending) -> None:
+        if pending is None:
+            return
+        work, k = pending
+        work.wait()
+        if self.rank == self.dst:
+            self.backend.untile(self.gathered[k], self.world, self.tiles_per_rank, self.framebuffer)
+
+    def finish(self) -> None:
+        """Drain the pipeline: after this ``framebuffer`` on rank dst holds the last frame."""
+        prev, self._pending = self._pending, None
+        self._complete(prev)
+
+    # ---- pieces, for measurement -----------------------------------------------------------
+    def project_only(self) -> None:
+        self.backend.project()
+
+    def trace_only(self) -> None:
+        """The k_trace launch of this rank's shard alone (projection already in the workspace)."""
+        b = self.backend
+        if self.world == 1:
+            b.trace(self.framebuffer, 0, 1, compact=False, projected=True)
+        elif self.local_tiles:
+            b.trace(self.compact[0], self.rank, self.world, compact=True, projected=True)

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Regenerates the golden fixtures in this directory from the fp64 oracle.
+
+    python tests/golden/make_golden.py
+
+The reference itself cannot run here (taichi is absent), so the vectors come from
+the repo's own restatements: oracle/rtgs_ref.py (NumPy, fp64) for everything it can finish, and
+oracle/rtgs_oracle.c (C, fp64) for the 100k-Gaussian c3 sample, cross-checked against the NumPy
+oracle on a 192-pixel subset before being written.  Inputs are NOT stored: every scene is
+regenerated from its seed by rtgs.synthetic / tests/scenes.py.  The reference's own fixture
+tests/data/test.ply is copied here as data (test_scene.py:16-23 loads it).
+"""
+
+import os
+import shutil
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+for p in (os.path.join(ROOT, "rt-gaussian-splat-renderer_amd"), ROOT, os.path.dirname(HERE)):
+    sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+import scenes  # noqa: E402
+from oracle import c_oracle  # noqa: E402
+from oracle import rtgs_ref as ref  # noqa: E402
+
+
+def numpy_render(arrays, cam, depth, pixels):
+    osc = ref.OracleScene(**arrays, dtype=np.float64)
+    return ref.render_topk(osc, cam["position"], cam["rotation"], cam["width"], cam["height"],
+                           cam["fx"], cam["fy"], depth=depth, pixels=pixels)
+
+
+def save(name, pixels, r):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, pixels=pixels.astype(np.int32), sample=r["sample"],
+                        attenuation=r["attenuation"], start=r["start"], hits=r["hits"].astype(np.int32),
+                        fragile=r["fragile"], margin_q=r["margin_q"], margin_t=r["margin_t"])
+    print(f"{name}: {pixels.shape[0]} px, mean hits {r['hits'].mean():.2f}, fragile "
+          f"{int(r['fragile'].sum())}, {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def main():
+    # c1: the full 128x128 image (config-1 full image + per-pixel hit counts)
+    arrays, cam, depth = scenes.config_case("c1")
+    pix = scenes.all_pixels(cam["width"], cam["height"])
+    save("c1_full", pix, numpy_render(arrays, cam, depth, pix))
+    # c2: centre crop + random pixels, NumPy oracle
+    arrays, cam, depth = scenes.config_case("c2")
+    pix = scenes.crop_pixels(cam["width"], cam["height"])
+    save("c2_crop", pix, numpy_render(arrays, cam, depth, pix))
+    # c3: same pixel pattern, C oracle, cross-checked against NumPy on a subset
+    arrays, cam, depth = scenes.config_case("c3")
+    pix = scenes.crop_pixels(cam["width"], cam["height"], extra=4096)
+    r = c_oracle.render(arrays, cam, depth, pix)
+    sub = np.arange(0, pix.shape[0], pix.shape[0] // 192)[:192]
+    chk = numpy_render(arrays, cam, depth, pix[sub])
+    assert np.abs(chk["sample"] - r["sample"][sub]).max() < 1e-9
+    assert (chk["hits"] == r["hits"][sub]).all()
+    save("c3_crop", pix, r)
+    # special cases, full frames
+    for name, fn in scenes.CASES.items():
+        arrays, cam, depth = fn()
+        pix = scenes.all_pixels(cam["width"], cam["height"])
+        save(name + "_full", pix, numpy_render(arrays, cam, depth, pix))
+    src = "/root/reference/tests/data/test.ply"
+    if os.path.exists(src):
+        shutil.copyfile(src, os.path.join(HERE, "test.ply"))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,78 @@
+"""Deterministic test scenes shared by the golden generator and the tests (inputs only)."""
+
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from rtgs import synthetic
+
+
+def quat_axis_angle(axis, angle):
+    axis = np.asarray(axis, dtype=np.float64)
+    axis = axis / np.linalg.norm(axis)
+    s = math.sin(angle / 2)
+    return tuple(float(np.float32(v)) for v in (axis[0] * s, axis[1] * s, axis[2] * s, math.cos(angle / 2)))
+
+
+def f32_tuple(values):
+    """Camera parameters cross the C ABI as fp32: keep test inputs exactly representable."""
+    return tuple(float(np.float32(v)) for v in values)
+
+
+def config_case(name):
+    cfg = synthetic.CONFIGS[name]
+    return synthetic.make_config_scene(cfg), synthetic.bench_camera(cfg.width, cfg.height), cfg.depth
+
+
+def oblique_case():
+    """Rotated camera, fx != fy, odd image size not a multiple of 32 or 8, N not a multiple of 64."""
+    arrays = synthetic.make_scene(1500, 1.4, 2024)
+    cam = dict(position=f32_tuple((0.7, -0.4, 2.6)), rotation=quat_axis_angle((0.3, 1.0, 0.2), 0.35),
+               width=150, height=101, fx=120.0, fy=135.0)
+    return arrays, cam, 16
+
+
+def inside_case():
+    """Camera INSIDE the cloud: Gaussians behind the camera, containing it, and crossing the
+    camera plane (the general-conic path of k_project)."""
+    arrays = synthetic.make_scene(800, 1.0, 77)
+    arrays["scale"] = (arrays["scale"] * np.float32(2.5)).astype(np.float32)
+    cam = dict(position=f32_tuple((0.1, 0.05, 0.2)), rotation=quat_axis_angle((1.0, 0.2, -0.4), 0.8),
+               width=96, height=80, fx=70.0, fy=70.0)
+    return arrays, cam, 16
+
+
+def sh_case():
+    """Degree-3 SH colour (the c5 shading path) at a size the oracle finishes quickly."""
+    arrays = synthetic.make_scene(3000, 16 / 9, 1005, sh=True)
+    cam = synthetic.bench_camera(192, 108)
+    cam["rotation"] = quat_axis_angle((0.0, 1.0, 0.0), 0.15)
+    cam["position"] = f32_tuple((0.5, 0.1, 2.9))
+    return arrays, cam, 16
+
+
+def shallow_case():
+    """depth < 16 and a dense scene: the depth cut is exercised on nearly every pixel."""
+    arrays = synthetic.make_scene(4000, 1.0, 31)
+    arrays["scale"] = (arrays["scale"] * np.float32(1.6)).astype(np.float32)
+    return arrays, synthetic.bench_camera(96, 96), 5
+
+
+CASES = {"oblique": oblique_case, "inside": inside_case, "sh": sh_case, "shallow": shallow_case}
+
+
+def crop_pixels(width, height, cw=64, ch=36, seed=7, extra=1024):
+    """A contiguous cw x ch crop around the image centre plus `extra` seeded random pixels."""
+    i0, j0 = width // 2 - cw // 2, height // 2 - ch // 2
+    i, j = np.meshgrid(np.arange(i0, i0 + cw), np.arange(j0, j0 + ch), indexing="ij")
+    crop = np.stack([i.ravel(), j.ravel()], axis=-1)
+    rng = np.random.default_rng(seed)
+    rnd = np.stack([rng.integers(0, width, extra), rng.integers(0, height, extra)], axis=-1)
+    return np.concatenate([crop, rnd]).astype(np.int32)
+
+
+def all_pixels(width, height):
+    i, j = np.meshgrid(np.arange(width), np.arange(height), indexing="ij")
+    return np.stack([i.ravel(), j.ravel()], axis=-1).astype(np.int32)

@@ -1,0 +1,135 @@
+"""CPU-side checks of the boundary: the C-ABI library loads and exports every symbol that
+include/rtgs_hip.h declares (no compute without a GPU), the pure-host entry points answer, and
+the host logic of the rtgs package (synthetic scenes, PLY ingest, vector types) behaves."""
+
+import os
+import re
+
+import numpy as np
+import pytest
+
+import scenes
+from oracle import rtgs_ref as ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "rtgs_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rtgs_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from rtgs import _native as nat
+    lib = nat.lib()
+    names = header_functions()
+    assert len(names) >= 17
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/rtgs_hip.h but not exported"
+    assert sorted(nat.PROTOTYPES) == names, "ctypes prototypes and header disagree"
+
+
+def test_pure_host_entry_points():
+    from rtgs import _native as nat
+    lib = nat.lib()
+    assert lib.rtgs_abi_version() == nat.ABI_VERSION == 1
+    assert lib.rtgs_strerror(0) == b"ok"
+    for code in (-1, -2, -3, -4, -5, -99):
+        assert len(lib.rtgs_strerror(code)) > 0
+    assert lib.rtgs_workspace_bytes(0) == 0 and lib.rtgs_workspace_bytes(-5) == 0
+    assert lib.rtgs_workspace_bytes(100_000) >= 100_000 * 96
+    assert lib.rtgs_num_tiles(1920, 1080) == 60 * 34
+    assert lib.rtgs_num_tiles(1, 1) == 1 and lib.rtgs_num_tiles(0, 5) == 0
+    total = lib.rtgs_num_tiles(1920, 1080)
+    assert sum(lib.rtgs_num_local_tiles(1920, 1080, r, 8) for r in range(8)) == total
+    assert lib.rtgs_num_local_tiles(1920, 1080, 0, 1) == total
+    assert lib.rtgs_num_local_tiles(32, 32, 3, 8) == 0      # more ranks than tiles
+    assert lib.rtgs_num_local_tiles(32, 32, 0, 0) == 0
+
+
+def test_argument_validation_needs_no_gpu():
+    # every entry point rejects NULL / non-positive sizes before touching the device
+    from rtgs import _native as nat
+    lib = nat.lib()
+    assert lib.rtgs_covariance(0, None, None, None, None, None) == -1
+    assert lib.rtgs_generate_rays(None, None, None) == -1
+    assert lib.rtgs_fill(None, 4, 0.0, None) == -1
+    assert lib.rtgs_quat_op(7, 1, None, None, None, None) == -1
+    assert lib.rtgs_untile(None, 1, 1, 4, 4, None, None) == -1
+    cam = nat.make_camera((0, 0, 0), (0, 0, 0, 1), 64, 64, 64.0, 64.0)
+    assert lib.rtgs_trace(None, cam, None, None, None, None, 1, None, 0, 0, None) == -1
+    with pytest.raises(ValueError):
+        nat.check(-2, "depth")
+    with pytest.raises(nat.RtgsError):
+        nat.check(-4, "launch")
+
+
+def test_device_tensors_are_required():
+    import torch
+    from rtgs import _native as nat
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        nat.require_device(torch.zeros(4), "x")
+
+
+def test_synthetic_scene_is_deterministic_and_as_specified():
+    from rtgs import synthetic
+    a = synthetic.make_scene(500, 16 / 9, 1003)
+    b = synthetic.make_scene(500, 16 / 9, 1003)
+    assert all(np.array_equal(a[k], b[k]) for k in a if a[k] is not None)
+    assert all(v.dtype == np.float32 for v in a.values() if v is not None)
+    assert np.abs(a["position"][:, 0]).max() <= 16 / 9 and np.abs(a["position"][:, 1:]).max() <= 1
+    assert np.linalg.norm(a["rotation"].astype(np.float64), axis=1) == pytest.approx(np.ones(500), abs=1e-6)
+    s0 = np.sqrt(8.727 * (16 / 9) / 500)
+    assert a["scale"].min() >= 0.5 * s0 * (1 - 1e-6) and a["scale"].max() <= 2 * s0 * (1 + 1e-6)
+    assert 0.1 <= a["opacity"].min() and a["opacity"].max() <= 0.9
+    assert a["sh"] is None and synthetic.make_scene(10, 1.0, 1, sh=True)["sh"].shape == (10, 15, 3)
+    # the algorithmic byte count of SURVEY.md 8(d)
+    assert synthetic.bytes_per_ray(100_000) == 56_518 and synthetic.bytes_per_ray(10_000) == 5_893
+    assert synthetic.bytes_per_ray(1_000_000, sh=True) == 565_648
+    cfg = synthetic.CONFIGS["c3"]
+    assert (cfg.n, cfg.width, cfg.height, cfg.rays) == (100_000, 1920, 1080, 2_073_600)
+
+
+def test_ply_reader_matches_the_oracle_reader():
+    from rtgs.scene import read_ply
+    mine = read_ply(os.path.join(GOLDEN, "test.ply"))
+    theirs = ref.read_ply_vertices(os.path.join(GOLDEN, "test.ply"))
+    assert list(mine) == list(theirs)
+    assert all(np.array_equal(mine[k], theirs[k]) for k in mine)
+    with pytest.raises(ValueError):
+        read_ply(os.path.join(GOLDEN, "c1_full.npz"))
+
+
+def test_vector_types():
+    from rtgs.utils.types import vec2i, vec3, vec4
+    v = vec3(1, 2, 3)
+    assert (v.x, v.y, v.z) == (1, 2, 3) and v == vec3([1, 2, 3]) and v != vec3(0)
+    assert vec3(0) == (0, 0, 0) and vec4(0, 0, 0, 1).w == 1
+    assert vec2i((960, 540)).x == 960 and vec2i((960, 540)).dtype == np.int32
+    with pytest.raises(ValueError):
+        vec3(1, 2)
+
+
+def test_records_have_the_reference_defaults():
+    # reference tests/test_ray.py:15-28 and tests/test_gaussian.py:16-39 (host constructors)
+    import math
+    from rtgs.gaussian import Gaussian, new_gaussian
+    from rtgs.ray import Ray, new_ray
+    from rtgs.utils.types import vec3, vec4
+    r = new_ray()
+    assert r.origin == vec3(0, 0, 0) and r.direction == vec3(0, 1, 0) and r.start == 0 and r.end == math.inf
+    r = new_ray(vec3(1, 2, 3), vec3(0, 0, 1), 1, 2)
+    assert r.origin == vec3(1, 2, 3) and r.direction == vec3(0, 0, 1) and (r.start, r.end) == (1, 2)
+    z = Ray()
+    assert z.origin == vec3(0) and z.direction == vec3(0) and z.start == 0 and z.end == 0
+    g = new_gaussian()
+    assert g.position == vec3(0) and g.rotation == vec4(0, 0, 0, 1) and g.scale == vec3(1, 1, 1)
+    assert g.color == vec3(1, 0, 1) and g.opacity == 1 and g.sh_36 == vec3(0)
+    g = new_gaussian(vec3(1, 2, 3), vec4(0, 0, 0.5, 0.5), vec3(2, 3, 4), vec3(1, 0, 0), 0.75)
+    assert g.scale == vec3(2, 3, 4) and g.opacity == 0.75
+    z = Gaussian()
+    assert z.rotation == vec4(0) and z.scale == vec3(0) and z.opacity == 0
+    with pytest.raises(NotImplementedError):
+        g.bounding_box()
