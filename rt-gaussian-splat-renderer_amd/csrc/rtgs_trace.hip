@@ -10,14 +10,15 @@
 // MI355X design (not the reference's: it walks a BVH per ray per peel with fp32 3x3 inverses):
 //   * k_project (once per frame, one thread per Gaussian, fp64 inside): the quadratic of
 //     gaussian.py:215-219 is factored per Gaussian.  With E = (X, Y, -1), X/Y the pixel-centre
-//     offsets from the image centre, delta/4 = E^T Q E is a conic in the image plane.  For an
-//     ellipsoid in front of the camera it is an ellipse; it is stored CENTRED
-//         delta/4 = K - (p00 x^2 + 2 p01 x y + p11 y^2),  (x, y) = (X, Y) - centre
-//     with the centre split hi+lo so the fp32 per-ray evaluation has no cancellation (the
-//     literal b^2 - A*C loses ~1e-3 relative for a 0.01-unit Gaussian 3 units away).  A and
-//     b = B/2 are stored as Taylor polynomials about the same centre.  Gaussians that contain
-//     the camera or lie behind it are culled here (they can never satisfy t1 > 0); conics that
-//     are not clean ellipses (ellipsoid crossing the camera plane) keep the general form.
+//     offsets from the image centre, delta/4 = E^T Q E is a conic in the image plane, and A and
+//     b = B/2 are a quadratic and a linear form in (X, Y).  All three are stored as their
+//     (exact) Taylor polynomials about an expansion point c on the half-integer pixel grid --
+//     the conic's centre clamped to the screen -- so that the fp32 per-ray evaluation works
+//     with small offsets (x, y) = (X, Y) - c and never forms the literal b^2 - A*C, which
+//     loses ~1e-3 relative for a 0.01-unit Gaussian 3 units away.  For an ellipsoid in front of
+//     the camera the conic is an ellipse and yields a screen bounding box; Gaussians that
+//     contain the camera or lie behind it are culled here (they can never satisfy t1 > 0);
+//     ellipsoids crossing the camera plane keep no bound and are decided per pixel by b < 0.
 //   * k_trace: one 1024-thread workgroup per 32x32 macro-tile, one wave64 per 8x8 pixel tile,
 //     one lane per ray.  The workgroup streams all screen bounds (16 B/Gaussian, SoA in HBM,
 //     L2-resident) in slabs; lanes test one Gaussian each against the macro-tile and compact
@@ -111,52 +112,57 @@ __global__ __launch_bounds__(256) void k_project(int32_t n, const float* __restr
     const double Q12 = v[1] * v[2] - C * Mc[1][2];
     const double Q22 = v[2] * v[2] - C * Mc[2][2];
     const double det = Q00 * Q11 - Q01 * Q01;
-    bool general = true;
-    if (Q00 < 0.0 && det > 0.0) {  // ellipse
-      const double X0 = (Q11 * Q02 - Q01 * Q12) / det;
-      const double Y0 = (Q00 * Q12 - Q01 * Q02) / det;
+    // Screen bound + visibility.  An ellipse (negative-definite 2x2 block) that reaches 0 and
+    // whose cone opens towards -z gets its bounding box; one that never reaches 0 or is the
+    // mirror cone behind the camera is culled; anything else (ellipsoid crossing the camera
+    // plane: hyperbola / parabola) is kept without a bound and sorted out per pixel by b < 0.
+    bool keep = true;
+    double X0 = 0.0, Y0 = 0.0;
+    bb = make_float4(-kInf, -kInf, kInf, kInf);
+    if (Q00 < 0.0 && det > 0.0) {
+      X0 = (Q11 * Q02 - Q01 * Q12) / det;
+      Y0 = (Q00 * Q12 - Q01 * Q02) / det;
       const double K = Q22 - (Q02 * X0 + Q12 * Y0);
-      const double hx = sqrt(K * (-Q11) / det);
-      const double hy = sqrt(K * (-Q00) / det);
-      const double lim = 4.0e6;  // beyond this the hi/lo split is no longer exact
-      if (K > 0.0 && fabs(X0) < lim && fabs(Y0) < lim && hx < lim && hy < lim) {
-        general = false;
-        const double b0 = v[0] * X0 + v[1] * Y0 - v[2];
-        if (b0 < 0.0) {  // in front of the camera (b0 >= 0: the mirror cone, t1 < 0)
-          const double pad_x = 1e-3 + 1e-5 * (fabs(X0) + hx);
-          const double pad_y = 1e-3 + 1e-5 * (fabs(Y0) + hy);
+      const double b0 = v[0] * X0 + v[1] * Y0 - v[2];
+      if (!(K > 0.0) || !(b0 < 0.0)) {
+        keep = false;
+      } else {
+        const double hx = sqrt(K * (-Q11) / det), hy = sqrt(K * (-Q00) / det);
+        const double pad_x = 1e-3 + 1e-5 * (fabs(X0) + hx), pad_y = 1e-3 + 1e-5 * (fabs(Y0) + hy);
+        if (hx < inf && hy < inf && fabs(X0) < inf && fabs(Y0) < inf)
           bb = make_float4((float)(X0 - hx - pad_x), (float)(Y0 - hy - pad_y),
                            (float)(X0 + hx + pad_x), (float)(Y0 + hy + pad_y));
-          const double xh = rint(2.0 * X0) * 0.5, yh = rint(2.0 * Y0) * 0.5;
-          const double e0 = Mc[0][0] * X0 + Mc[0][1] * Y0 - Mc[0][2];
-          const double e1 = Mc[1][0] * X0 + Mc[1][1] * Y0 - Mc[1][2];
-          const double e2 = Mc[2][0] * X0 + Mc[2][1] * Y0 - Mc[2][2];
-          r[0] = (float)xh;        r[1] = (float)yh;
-          r[2] = (float)(X0 - xh); r[3] = (float)(Y0 - yh);
-          r[4] = (float)(-Q00);    r[5] = (float)(-2.0 * Q01);
-          r[6] = (float)(-Q11);    r[7] = (float)K;
-          r[8] = (float)(X0 * e0 + Y0 * e1 - e2);  // A at the centre
-          r[9] = (float)(2.0 * e0); r[10] = (float)(2.0 * e1);
-          r[11] = (float)Mc[0][0]; r[12] = (float)(2.0 * Mc[0][1]);
-          r[13] = (float)Mc[1][1];
-          r[14] = (float)b0;       r[15] = (float)v[0];
-          r[16] = (float)v[1];     r[17] = __int_as_float(0);
-        }
-      } else if (!(K > 0.0)) {
-        general = false;  // negative-definite conic that never reaches 0: no pixel hits
       }
     }
-    if (general && C < inf) {
-      // Ellipsoid crossing the camera plane (or a degenerate conic): keep the quadratic of
-      // gaussian.py:215-219 in camera coordinates.  Such Gaussians are near the camera, where
-      // the direct form is well conditioned.  No screen bound.
-      bb = make_float4(-kInf, -kInf, kInf, kInf);
-      r[0] = (float)Mc[0][0];         r[1] = (float)(2.0 * Mc[0][1]);
-      r[2] = (float)(2.0 * Mc[0][2]); r[3] = (float)Mc[1][1];
-      r[4] = (float)(2.0 * Mc[1][2]); r[5] = (float)Mc[2][2];
-      r[6] = (float)v[0]; r[7] = (float)v[1]; r[8] = (float)v[2];
-      r[9] = (float)C;
-      r[17] = __int_as_float(1);
+    if (keep && C < inf) {
+      // Expansion point: the conic centre snapped to the half-integer pixel-centre grid and
+      // clamped to the screen, so that (X - cx) is exact in fp32 and every on-screen pixel is
+      // evaluated close to it.  A quadratic's Taylor expansion is exact about any point.
+      const double hw = 0.5 * cam.width, hh = 0.5 * cam.height;
+      double cx = (X0 == X0 && fabs(X0) < inf) ? X0 : 0.0;
+      double cy = (Y0 == Y0 && fabs(Y0) < inf) ? Y0 : 0.0;
+      cx = fmin(fmax(cx, -hw), hw);
+      cy = fmin(fmax(cy, -hh), hh);
+      cx = rint(2.0 * cx) * 0.5;
+      cy = rint(2.0 * cy) * 0.5;
+      // E_c = (cx, cy, -1)
+      const double q0 = Q00 * cx + Q01 * cy - Q02, q1 = Q01 * cx + Q11 * cy - Q12,
+                   q2 = Q02 * cx + Q12 * cy - Q22;
+      const double e0 = Mc[0][0] * cx + Mc[0][1] * cy - Mc[0][2];
+      const double e1 = Mc[1][0] * cx + Mc[1][1] * cy - Mc[1][2];
+      const double e2 = Mc[2][0] * cx + Mc[2][1] * cy - Mc[2][2];
+      r[0] = (float)cx;              r[1] = (float)cy;
+      r[2] = (float)(cx * q0 + cy * q1 - q2);      // delta/4 at the expansion point
+      r[3] = (float)(2.0 * q0);      r[4] = (float)(2.0 * q1);   // its gradient
+      r[5] = (float)(-Q00);          r[6] = (float)(-2.0 * Q01); r[7] = (float)(-Q11);
+      r[8] = (float)(cx * e0 + cy * e1 - e2);      // A at the expansion point
+      r[9] = (float)(2.0 * e0);      r[10] = (float)(2.0 * e1);
+      r[11] = (float)Mc[0][0];       r[12] = (float)(2.0 * Mc[0][1]); r[13] = (float)Mc[1][1];
+      r[14] = (float)(v[0] * cx + v[1] * cy - v[2]);  // b = B/2 at the expansion point
+      r[15] = (float)v[0];           r[16] = (float)v[1];
+      r[17] = (float)C;
+    } else {
+      bb = make_float4(kInf, kInf, -kInf, -kInf);
     }
   }
   bbox[g] = bb;
@@ -323,33 +329,25 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const TraceArgs a) {
           const int b = __builtin_ctzll(m);
           m &= m - 1;
           const int gi = __builtin_amdgcn_readlane(g, b);
-          const int type = __builtin_amdgcn_readlane(__float_as_int(r4.y), b);
-          float e, A, bq;
-          bool hit;
-          if (type == 0) {
-            const float x = (X - bcast(r0.x, b)) - bcast(r0.z, b);
-            const float y = (Y - bcast(r0.y, b)) - bcast(r0.w, b);
-            const float quad = (bcast(r1.x, b) * x + bcast(r1.y, b) * y) * x + (bcast(r1.z, b) * y) * y;
-            e = bcast(r1.w, b) - quad;                      // delta/4
-            hit = e > 0.f && in_img;
-            if (!__any(hit)) continue;
-            A = bcast(r2.x, b) + bcast(r2.y, b) * x + bcast(r2.z, b) * y +
-                (bcast(r2.w, b) * x + bcast(r3.x, b) * y) * x + (bcast(r3.y, b) * y) * y;
-            bq = bcast(r3.z, b) + bcast(r3.w, b) * x + bcast(r4.x, b) * y;
-          } else {
-            A = (bcast(r0.x, b) * X + bcast(r0.y, b) * Y - bcast(r0.z, b)) * X +
-                (bcast(r0.w, b) * Y - bcast(r1.x, b)) * Y + bcast(r1.y, b);
-            bq = bcast(r1.z, b) * X + bcast(r1.w, b) * Y - bcast(r2.x, b);
-            e = bq * bq - A * bcast(r2.y, b);
-            hit = e > 0.f && bq < 0.f && in_img;
-            if (!__any(hit)) continue;
-          }
-          const float rA = 1.0f / A;
-          const float t1 = ((-bq - sqrtf(e)) * rA) * dlen;   // gaussian.py:224
+          // delta/4 = e_c + g.(x,y) - (x,y) P (x,y)^T about the record's expansion point
+          const float x = X - bcast(r0.x, b);
+          const float y = Y - bcast(r0.y, b);
+          const float e = bcast(r0.z, b) -
+                          ((bcast(r1.y, b) * x + bcast(r1.z, b) * y - bcast(r0.w, b)) * x +
+                           (bcast(r1.w, b) * y - bcast(r1.x, b)) * y);
+          bool hit = e > 0.f && in_img;
+          if (!__any(hit)) continue;
+          const float A = bcast(r2.x, b) + bcast(r2.y, b) * x + bcast(r2.z, b) * y +
+                          (bcast(r2.w, b) * x + bcast(r3.x, b) * y) * x + (bcast(r3.y, b) * y) * y;
+          const float bq = bcast(r3.z, b) + bcast(r3.w, b) * x + bcast(r4.x, b) * y;
+          hit = hit && bq < 0.f;   // the cone half in front of the camera
+          // smaller root of A t^2 + 2 b t + C (gaussian.py:224) in its cancellation-free form
+          // t1 = C / (sqrt(delta/4) - b): C > 0 and b < 0, so nothing is subtracted
+          const float t1 = (bcast(r4.y, b) / (sqrtf(e) - bq)) * dlen;
           const bool cand = hit && t1 > start && t1 < kInf;  // scene.py:433
           const unsigned long long kn =
               cand ? (((unsigned long long)__float_as_uint(t1) << 32) | (unsigned)gi) : ~0ull;
-          if (__any(kn < key[RTGS_MAX_DEPTH - 1])) list_insert(key, wexp, kn, e * rA);
+          if (__any(kn < key[RTGS_MAX_DEPTH - 1])) list_insert(key, wexp, kn, e / A);
         }
       }
     }

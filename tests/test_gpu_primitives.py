@@ -1,0 +1,228 @@
+"""-m gpu: the device mirrors of the reference's primitives, checked against the reference's own
+known answers (tests/test_quaternion.py, test_ray.py, test_gaussian.py, test_scene.py) and
+against the oracle on seeded inputs."""
+
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import gpu_util as U
+import rtgs
+import rtgs.utils.quaternion as quat
+from oracle import rtgs_ref as ref
+from rtgs import _native as nat
+from rtgs.gaussian import Gaussian, new_gaussian
+from rtgs.ray import Ray, new_ray
+from rtgs.utils.types import vec3, vec4
+
+pytestmark = pytest.mark.gpu
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+# ---- quaternion (reference tests/test_quaternion.py) ----
+
+def test_quat_known_answers():
+    assert np_(quat.mul((1, -2, 1, 3), (-1, 2, 3, 2))).tolist() == [-9, -2, 11, 8]      # :25-29
+    assert np_(quat.conj((1, 2, 3, 4))).tolist() == [-1, -2, -3, 4]                      # :40-43
+    q = (1.0, 2.0, 3.0, 4.0)                                                             # :58-62, literal
+    assert np_(quat.mul(q, quat.inv(q))) == pytest.approx([0, 0, 0, math.sqrt(30)], abs=1e-5)
+    v = (0.0, math.pi, 0.0)                                                              # :81-90
+    qa = quat.from_axis_angle(v)
+    assert np_(qa) == pytest.approx([0, 1, 0, 0], abs=1e-6)
+    assert np_(quat.as_axis_angle(qa)) == pytest.approx(v, abs=1e-6)
+    qz = quat.from_axis_angle((0, 0, math.pi / 2))                                       # :107-118
+    assert np_(quat.rot_vec3(qz, (1, 0, 0))) == pytest.approx([0, 1, 0], abs=1e-6)
+    qy = quat.from_axis_angle((0, math.pi / 2, 0))
+    assert np_(quat.rot_vec3(qy, (1, 0, 0))) == pytest.approx([0, 0, -1], abs=1e-6)
+
+
+def test_rotation_matrices_match_rot_vec3_and_oracle():
+    rng = np.random.default_rng(42)                                                       # :147-153, 182-188
+    q = rng.normal(size=(64, 4)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    v = rng.normal(size=(64, 3)).astype(np.float32)
+    m3, m4, rv = np_(quat.as_rotation_mat3(q)), np_(quat.as_rotation_mat4(q)), np_(quat.rot_vec3(q, v))
+    assert np.einsum("nij,nj->ni", m3, v) == pytest.approx(rv, abs=1e-6)
+    assert np.einsum("nij,nj->ni", m4[:, :3, :3], v) == pytest.approx(rv, abs=1e-6)
+    assert m3 == pytest.approx(ref.quat_as_rotation_mat3(q.astype(np.float64)), abs=1e-6)
+    p = rng.normal(size=(64, 4)).astype(np.float32)
+    assert np_(quat.mul(p, q)) == pytest.approx(ref.quat_mul(p.astype(np.float64), q.astype(np.float64)), abs=1e-5)
+
+
+# ---- ray (reference tests/test_ray.py) ----
+
+def test_ray_field_and_get():
+    f = Ray.field(shape=(4, 4))                                                          # :31-50
+    assert f.shape == (4, 4)
+    r = f[0, 0]
+    assert r.origin == vec3(0) and r.direction == vec3(0) and r.start == 0 and r.end == 0
+    f.init()
+    r = f[3, 2]
+    assert r.origin == vec3(0) and r.direction == vec3(0, 1, 0) and r.start == 0 and math.isinf(r.end)
+    rng = np.random.default_rng(42)                                                      # :53-116
+    f.data[..., :6] = torch.from_numpy(rng.random((4, 4, 6)).astype(np.float32)).cuda()
+    t = rng.random((4, 4)).astype(np.float32)
+    got = np_(f.get(t))
+    o, d = np_(f.origin), np_(f.direction)
+    assert got == pytest.approx(o + t[..., None] * d, abs=1e-6)
+    one = f[1, 2]
+    assert one.get(0.5) == vec3(got[1, 2] * 0 + (one.origin + np.float32(0.5) * one.direction))
+    f[0, 1] = new_ray(vec3(1, 2, 3), vec3(0, 0, 1), 1, 2)
+    assert f[0, 1].origin == vec3(1, 2, 3) and f[0, 1].end == 2
+
+
+# ---- gaussian (reference tests/test_gaussian.py) ----
+
+def test_gaussian_field_defaults():
+    f = Gaussian.field(shape=(32,))                                                      # :42-63
+    assert f.shape == (32,)
+    g = f[0]
+    assert g.position == vec3(0) and g.rotation == vec4(0) and g.scale == vec3(0) and g.opacity == 0
+    f.init()
+    g = f[31]
+    assert g.rotation == vec4(0, 0, 0, 1) and g.scale == vec3(1, 1, 1) and g.color == vec3(1, 0, 1) and g.opacity == 1
+    f[5] = new_gaussian(vec3(1, 2, 3), vec4(0, 0, 0, 1), vec3(2, 3, 4), vec3(1, 0, 0), 0.75)
+    assert f[5].position == vec3(1, 2, 3) and f[5].opacity == 0.75
+
+
+def test_gaussian_hit_of_the_default_gaussian():
+    # tests/test_gaussian.py:65-84 states (0, inf); gaussian.py:215-226 evaluates to -/+ sqrt(3)
+    g = new_gaussian()
+    h = g.hit(new_ray())
+    assert (h.x, h.y) == pytest.approx((-math.sqrt(3), math.sqrt(3)), abs=1e-6)
+    h = g.hit(new_ray(vec3(0, 0, 0), vec3(0, 1, 0), 0, 1))
+    assert (h.x, h.y) == pytest.approx((-math.sqrt(3), math.sqrt(3)), abs=1e-6)
+    miss = g.hit(new_ray(vec3(5, 0, 0), vec3(0, 1, 0)))
+    assert math.isinf(miss.x) and math.isinf(miss.y)
+
+
+def test_cov_hit_eval_match_the_oracle():
+    rng = np.random.default_rng(7)
+    for _ in range(8):
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        g = new_gaussian(rng.normal(size=3), q, rng.uniform(0.2, 1.5, 3), rng.random(3), rng.uniform(0.1, 0.9))
+        for k, name in enumerate(rtgs.gaussian.SH_NAMES):
+            setattr(g, name, vec3(rng.uniform(-0.3, 0.3, 3)))
+        pos64, rot64, sc64 = (np.asarray(a, np.float64) for a in (g.position, g.rotation, g.scale))
+        assert g.cov() == pytest.approx(ref.gaussian_cov(rot64, sc64), rel=2e-6, abs=1e-7)
+        minv = ref.gaussian_cov_inv(rot64, sc64)
+        o, d = rng.normal(size=3).astype(np.float32), rng.normal(size=3).astype(np.float32)
+        t1, t2 = ref.gaussian_hit(o.astype(np.float64), d.astype(np.float64), pos64, minv)
+        h = g.hit(new_ray(o, d))
+        if np.isfinite(t1):
+            assert (h.x, h.y) == pytest.approx((float(t1), float(t2)), rel=1e-5, abs=1e-5)
+        else:
+            assert math.isinf(h.x)
+        x = (pos64 + rng.normal(size=3) * 0.5).astype(np.float32)
+        rgb, alpha = ref.gaussian_eval(x.astype(np.float64), d.astype(np.float64), pos64, minv,
+                                       np.asarray(g.color, np.float64), g.opacity, g.sh_array().astype(np.float64))
+        e = g.eval(x, d)
+        assert np.asarray(e)[:3] == pytest.approx(rgb, abs=2e-6) and e.w == pytest.approx(alpha, rel=2e-5, abs=1e-7)
+        dn = d / np.linalg.norm(d)
+        assert np.asarray(g.eval_sh(dn)) == pytest.approx(
+            ref.gaussian_eval_sh(dn.astype(np.float64), g.sh_array().astype(np.float64)), abs=2e-6)
+
+
+# ---- camera ----
+
+def test_generate_ray_field_matches_the_oracle():
+    arrays, cam, _ = U.case("oblique")
+    camera = rtgs.Camera(cam["position"], cam["rotation"], (cam["width"], cam["height"]), (cam["fx"], cam["fy"]))
+    camera.generate_ray_field(camera.position, camera.rotation)
+    rays = np_(camera.cam_ray_field.data)
+    _, d = ref.generate_rays(cam["position"], cam["rotation"], cam["width"], cam["height"], cam["fx"], cam["fy"])
+    assert rays[..., 3:6].reshape(-1, 3) == pytest.approx(d, abs=3e-7)
+    assert (rays[..., 0:3] == np.asarray(cam["position"], np.float32)).all()
+    assert (rays[..., 6] == 0).all() and np.isinf(rays[..., 7]).all()
+    one = camera.generate_ray(camera.position, camera.rotation, (0.5, 0.25))
+    _, d1 = ref.generate_rays(cam["position"], cam["rotation"], 2, 4, cam["fx"] * 2 / cam["width"],
+                              cam["fy"] * 4 / cam["height"], pixels=[[0, 0]])
+    # uv (0.5, 0.25) of the (150, 101) sensor: pxy = ((0.5-0.5)*150/fx, (0.25-0.5)*101/fy)
+    want = np.array([0.0, -0.25 * cam["height"] / cam["fy"], -1.0])
+    want = ref.quat_rot_vec3(np.asarray(cam["rotation"]), want / np.linalg.norm(want))
+    assert np.asarray(one.direction) == pytest.approx(want, abs=3e-7)
+
+
+# ---- scene ----
+
+def test_scene_hit_matches_the_oracle():
+    arrays, cam, _ = U.case("c1")
+    scene = rtgs.Scene.from_arrays(**arrays)
+    osc = ref.OracleScene(**arrays)
+    rng = np.random.default_rng(13)
+    n = 3000
+    o = rng.uniform(-1.5, 1.5, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    start = rng.uniform(0, 0.5, n).astype(np.float32)
+    end = np.where(rng.random(n) < 0.3, rng.uniform(0.5, 3.0, n), np.inf).astype(np.float32)
+    rays = np.concatenate([o, d, start[:, None], end[:, None]], axis=1).astype(np.float32)
+    idx, t = scene.hit_batch(torch.from_numpy(rays).cuda())
+    wi, wt1, wt2 = ref.closest_hit(osc, o.astype(np.float64), d.astype(np.float64), start.astype(np.float64),
+                                   end.astype(np.float64))
+    idx, t = np_(idx), np_(t)
+    assert (idx == wi).mean() >= 0.999          # fp32 rounding of the returned t may flip a near-tie
+    same = idx == wi
+    hit = same & (wi >= 0)
+    assert hit.sum() > 500 and (wi < 0).sum() > 50
+    assert t[hit, 0] == pytest.approx(wt1[hit], rel=1e-6, abs=1e-6)
+    assert t[hit, 1] == pytest.approx(wt2[hit], rel=1e-6, abs=1e-6)
+    assert np.isinf(t[same & (wi < 0)]).all()
+    k = int(np.nonzero(hit)[0][0])
+    single = scene.hit(Ray.from_array(rays[k]))
+    assert single.gaussian_idx == wi[k] and single.intersections.x == pytest.approx(wt1[k], rel=1e-6)
+    assert scene.hit(new_ray(vec3(50, 50, 50), vec3(0, 1, 0))).gaussian_idx == -1
+
+
+def test_scene_load_file():
+    # reference tests/test_scene.py:16-23: loading tests/data/test.ply must not raise
+    path = os.path.join(U.GOLDEN, "test.ply")
+    scene = rtgs.Scene()
+    scene.load_file(__import__("pathlib").Path(path))
+    want = ref.load_ply_gaussians(path)
+    f = scene.gaussian_field
+    assert f.n == 16
+    for name in ("position", "rotation", "scale", "color", "opacity", "sh"):
+        assert np_(getattr(f, name)) == pytest.approx(want[name], rel=2e-6, abs=1e-7), name
+    # inverse covariance of the loaded Gaussians vs the oracle (scales down to 4e-4 -> 6e6 entries)
+    minv = ref.gaussian_cov_inv(np_(f.rotation).astype(np.float64), np_(f.scale).astype(np.float64))
+    c = np_(scene.cov_inv6)
+    got = np.stack([c[:, [0, 1, 2]], c[:, [1, 3, 4]], c[:, [2, 4, 5]]], axis=1)
+    assert got == pytest.approx(minv, rel=5e-6)
+    scene2 = rtgs.Scene()
+    scene2.load_file(__import__("pathlib").Path(path), 2.0)
+    assert np_(scene2.gaussian_field.scale) == pytest.approx(2 * want["scale"], rel=2e-6)
+
+
+def test_ply_scene_renders_like_the_oracle():
+    from oracle import c_oracle
+    path = os.path.join(U.GOLDEN, "test.ply")
+    scene = rtgs.Scene()
+    scene.load_file(__import__("pathlib").Path(path), 8.0)      # --scale 8 makes the 16 splats visible
+    f = scene.gaussian_field
+    arrays = {k: np_(getattr(f, k)) for k in ("position", "rotation", "scale", "color", "opacity", "sh")}
+    cam = dict(position=(0.3, 0.0, 3.0), rotation=(0.0, 0.0, 0.0, 1.0), width=96, height=64, fx=60.0, fy=60.0)
+    cam["position"] = tuple(float(np.float32(v)) for v in cam["position"])
+    camera = rtgs.Camera(cam["position"], cam["rotation"], (96, 64), (60.0, 60.0))
+    tracer = rtgs.RayTracer((96, 64), scene, camera)
+    tracer.sample_all(16)
+    want = c_oracle.render(arrays, cam, 16, eps_q=1e-4)
+    assert np.abs(want["sample"]).max() > 0.05
+    U.assert_parity(np_(tracer.sample_buf).reshape(-1, 3), want, "test.ply")
+
+
+def test_disp_and_fill():
+    arrays, cam, depth = U.case("c1")
+    _, _, tr = U.build(arrays, cam)
+    tr.sample_buf.fill_(6.0)
+    tr.generate_disp_buffer(1, 8, 16)
+    assert float((tr.disp_buf - 4.0).abs().max()) == 0.0
+    tr.clear_attenuation()
+    assert float(tr.attenuation_buf.min()) == 1.0 == float(tr.attenuation_buf.max())
