@@ -144,7 +144,7 @@ def main():
         ms = elapsed / args.steps * 1e3
         mrays = cfg.rays / (elapsed / args.steps) / 1e6
         bpr = synthetic.bytes_per_ray(cfg.n, cfg.sh, cfg.depth)
-        local_rays = renderer.local_tiles * nat.TILE * nat.TILE
+        local_rays = renderer.local_tiles * nat.tile_size() ** 2
         achieved = bpr * min(local_rays, cfg.rays) / (trace_ms * 1e-3) / 1e9  # GB/s, this rank's launch
         line = {
             "metric": "Mrays/s at 1920x1080, 100k Gaussians; achieved HBM GB/s vs peak",

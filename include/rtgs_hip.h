@@ -33,7 +33,9 @@ extern "C" {
 
 #define RTGS_ABI_VERSION 1
 #define RTGS_MAX_DEPTH 16        /* peels kept per ray in one pass (__main__.py:70 default) */
-#define RTGS_TILE 32             /* macro-tile edge in pixels: the unit of sharding */
+#ifndef RTGS_TILE
+#define RTGS_TILE 16             /* macro-tile edge in pixels: one workgroup, the unit of sharding */
+#endif
 #define RTGS_RAY_FLOATS 8        /* Ray = origin3, direction3, start, end (ray.py:4-18) */
 #define RTGS_SH_COEFFS 15        /* sh_10 .. sh_36 (gaussian.py:41-55) */
 
@@ -72,7 +74,7 @@ typedef struct RtgsCamera {
                                      in progress); otherwise start = 0, attenuation = 1      */
 #define RTGS_TRACE_ACCUMULATE 2u  /* sample_buf += radiance (ray_tracer.py:95); otherwise the
                                      shard's pixels are overwritten                          */
-#define RTGS_TRACE_COMPACT 4u     /* sample_buf is the shard-compact [local_tile][32][32][3]
+#define RTGS_TRACE_COMPACT 4u     /* sample_buf is the shard-compact [local_tile][T][T][3], T = rtgs_tile_size(),
                                      buffer that rtgs_untile scatters, not the (W,H,3) image  */
 
 typedef struct RtgsTraceParams {
@@ -100,7 +102,9 @@ int rtgs_generate_rays(const RtgsCamera* cam, float* rays /*[W][H][8]*/, rtgs_st
 /* Bytes of scratch rtgs_trace needs for n Gaussians (per-frame projected records). */
 size_t rtgs_workspace_bytes(int32_t n);
 
-/* Number of 32x32 macro-tiles of a W x H image, and how many of them a shard owns. */
+/* Macro-tile edge the library was built with, the number of macro-tiles of a W x H image, and
+ * how many of them a shard owns. */
+int32_t rtgs_tile_size(void);
 int32_t rtgs_num_tiles(int32_t width, int32_t height);
 int32_t rtgs_num_local_tiles(int32_t width, int32_t height, int32_t tile_first, int32_t tile_step);
 
@@ -128,7 +132,7 @@ int rtgs_project(const RtgsScene* scene, const RtgsCamera* cam, void* workspace,
                  size_t workspace_bytes, rtgs_stream_t stream);
 
 /* Tile-parallel epilogue: scatter gathered shard-compact buffers
- * compact[rank][local_tile][32][32][3] (rank-major, `tiles_per_rank` tiles each, as produced
+ * compact[rank][local_tile][T][T][3], T = rtgs_tile_size(), (rank-major, `tiles_per_rank` tiles each, as produced
  * by RTGS_TRACE_COMPACT with (tile_first, tile_step) = (rank, world)) into image [W][H][3]. */
 int rtgs_untile(const float* compact, int32_t world, int32_t tiles_per_rank, int32_t width,
                 int32_t height, float* image, rtgs_stream_t stream);

@@ -17,8 +17,8 @@ constexpr int kWave = 64;          // CDNA wavefront
 constexpr int kTile = RTGS_TILE;   // macro-tile edge (pixels) = one workgroup
 constexpr int kWaveTile = 8;       // one wave64 owns an 8x8 pixel tile
 constexpr int kWavesX = kTile / kWaveTile;
-constexpr int kWavesPerTile = kWavesX * kWavesX;  // 16
-constexpr int kTraceBlock = kWavesPerTile * kWave;  // 1024 threads
+constexpr int kWavesPerTile = kWavesX * kWavesX;
+constexpr int kTraceBlock = kWavesPerTile * kWave;  // 256 threads for a 16x16 macro-tile
 constexpr int kRecFloats = 20;     // per-frame projected record, 80 B, 16-B aligned
 constexpr float kInf = __builtin_huge_valf();
 

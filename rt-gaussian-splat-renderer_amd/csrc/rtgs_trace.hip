@@ -19,23 +19,31 @@
 //     the camera the conic is an ellipse and yields a screen bounding box; Gaussians that
 //     contain the camera or lie behind it are culled here (they can never satisfy t1 > 0);
 //     ellipsoids crossing the camera plane keep no bound and are decided per pixel by b < 0.
-//   * k_trace: one 1024-thread workgroup per 32x32 macro-tile, one wave64 per 8x8 pixel tile,
-//     one lane per ray.  The workgroup streams all screen bounds (16 B/Gaussian, SoA in HBM,
-//     L2-resident) in slabs; lanes test one Gaussian each against the macro-tile and compact
-//     survivors into an LDS list with wave ballots.  Each wave then re-tests the survivors
-//     against its own 8x8 tile (one survivor per lane, ballot), and for every set bit all 64
-//     rays evaluate the exact conic.  Hits go into a per-lane sorted register list of the
-//     `RTGS_MAX_DEPTH` nearest (t1, index) -- the reference's `depth` peels in one pass -- and
-//     are composited front to back at the end; a wave ballot ends the compositing loop early
-//     when every lane is below the transmittance cut-off.  No MFMA: there is no contraction.
+//     Gaussians are streamed in SLABS of 64 consecutive records (one wave of k_project); the
+//     wave also reduces the slab's union screen bound.  With the scene stored in Morton order
+//     (rtgs.Scene does that at load) a slab is spatially compact, so its bound is tight.
+//   * k_trace: one workgroup per RTGS_TILE x RTGS_TILE macro-tile, one wave64 per 8x8 pixel
+//     tile, one lane per ray.  The workgroup scans the slab bounds (16 B per 64 Gaussians),
+//     keeps the slabs that touch the macro-tile (deterministic ballot/prefix compaction into
+//     LDS), expands them -- one wave per slab, one lane per Gaussian, 16 B bounds, SoA in HBM --
+//     and compacts the surviving Gaussians into an LDS list.  Each wave then re-tests the
+//     survivors against its own 8x8 tile (one survivor per lane, ballot) and, for every set
+//     bit, all 64 rays evaluate the exact conic with the record broadcast by v_readlane.  Hits
+//     go into a per-lane sorted register list of the RTGS_MAX_DEPTH nearest (t1, index) -- the
+//     reference's `depth` peels in one pass -- and are composited front to back at the end; a
+//     wave ballot ends the compositing loop early when every lane is below the transmittance
+//     cut-off.  No MFMA: there is no contraction anywhere on this path.
 #include "rtgs_common.hpp"
 
 namespace rtgs {
 namespace {
 
-constexpr int kStreamIters = 4;                          // bounds loads in flight per thread
-constexpr int kSuper = kStreamIters * kTraceBlock;       // Gaussians streamed per barrier
-constexpr int kListCap = 2 * kSuper;                     // LDS survivor list (indices)
+constexpr int kSlab = 64;                                 // Gaussians per slab = one wave
+constexpr int kSlabIters = 2048 / kTraceBlock;            // slab bounds in flight per thread
+constexpr int kSlabChunk = kSlabIters * kTraceBlock;      // slabs scanned per barrier (2048)
+constexpr int kSlabCap = kSlabChunk;                      // LDS list of surviving slabs
+constexpr int kListCap = 2048;                            // LDS list of surviving Gaussians
+constexpr int kBatch = kListCap / kSlab;                  // slabs expanded per batch
 
 struct TraceArgs {
   int32_t n;
@@ -48,6 +56,7 @@ struct TraceArgs {
   float inv_fx, inv_fy;
   float rc[9];  // camera rotation, for the SH direction only
   const float4* __restrict__ bbox;
+  const float4* __restrict__ slab_bbox;
   const float* __restrict__ rec;
   const float4* __restrict__ colop;
   const float* __restrict__ sh;
@@ -64,9 +73,11 @@ struct TraceArgs {
 __global__ __launch_bounds__(256) void k_project(int32_t n, const float* __restrict__ pos,
                                                   const float* __restrict__ ci6, FrameCam cam,
                                                   float4* __restrict__ bbox,
+                                                  float4* __restrict__ slab_bbox,
                                                   float* __restrict__ rec) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= n) return;
+  const int g0 = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = g0 < n;
+  const int g = live ? g0 : n - 1;   // padding lanes recompute the last record, store nothing
   const double inf = __builtin_huge_val();
   float4 bb = make_float4(kInf, kInf, -kInf, -kInf);  // empty: culled
   float r[kRecFloats];
@@ -165,11 +176,22 @@ __global__ __launch_bounds__(256) void k_project(int32_t n, const float* __restr
       bb = make_float4(kInf, kInf, -kInf, -kInf);
     }
   }
-  bbox[g] = bb;
-  float4* out = reinterpret_cast<float4*>(rec + (size_t)g * kRecFloats);
+  if (live) {
+    bbox[g] = bb;
+    float4* out = reinterpret_cast<float4*>(rec + (size_t)g * kRecFloats);
 #pragma unroll
-  for (int k = 0; k < kRecFloats / 4; ++k)
-    out[k] = make_float4(r[4 * k], r[4 * k + 1], r[4 * k + 2], r[4 * k + 3]);
+    for (int k = 0; k < kRecFloats / 4; ++k)
+      out[k] = make_float4(r[4 * k], r[4 * k + 1], r[4 * k + 2], r[4 * k + 3]);
+  }
+  // union bound of the slab (= this wave's 64 Gaussians); culled members are empty boxes
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    bb.x = fminf(bb.x, __shfl_xor(bb.x, off));
+    bb.y = fminf(bb.y, __shfl_xor(bb.y, off));
+    bb.z = fmaxf(bb.z, __shfl_xor(bb.z, off));
+    bb.w = fmaxf(bb.w, __shfl_xor(bb.w, off));
+  }
+  if ((threadIdx.x & (kWave - 1)) == 0 && live) slab_bbox[g0 / kSlab] = bb;
 }
 
 // ------------------------------------------------------------------------------------
@@ -221,9 +243,11 @@ __device__ __forceinline__ void sh_basis(float x, float y, float z, float (&Y)[R
 }
 
 template <bool kHasSh>
-__global__ __launch_bounds__(kTraceBlock) void k_trace(const TraceArgs a) {
+__global__ __launch_bounds__(kTraceBlock, 4) void k_trace(const TraceArgs a) {
+  __shared__ int s_slab[kSlabCap];
   __shared__ int s_idx[kListCap];
   __shared__ int s_wcnt[2][kWavesPerTile];
+  __shared__ int s_n;
 
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
@@ -266,93 +290,112 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const TraceArgs a) {
 #pragma unroll
   for (int k = 0; k < RTGS_MAX_DEPTH; ++k) { key[k] = kEmpty; wexp[k] = 0.f; }
 
-  // Survivor list bookkeeping is deterministic and atomic-free: every wave publishes how many
-  // Gaussians of the super-slab it keeps, one barrier later every thread derives the same
-  // offsets and the same running count `cnt` (kept in a register, identical in all threads).
-  // s_wcnt is double-buffered by super-slab parity: waves are never more than one barrier apart.
-  int cnt = 0;
   const unsigned long long lane_lt = (1ull << lane) - 1ull;
+  const int nslabs = (a.n + kSlab - 1) / kSlab;
 
-  for (int base = 0, par = 0; base < a.n; base += kSuper, par ^= 1) {
-    // ---- stream one super-slab of screen bounds, keep what touches the macro-tile ----
-    float4 bb[kStreamIters];
+  for (int sbase = 0, par = 0; sbase < nslabs; sbase += kSlabChunk, par ^= 1) {
+    // ---- scan a chunk of slab bounds; keep the slabs that touch the macro-tile.  The list is
+    // built without atomics: every wave publishes its count, one barrier later every thread
+    // derives the same offsets (s_wcnt is double-buffered by chunk parity).
+    float4 sb[kSlabIters];
 #pragma unroll
-    for (int it = 0; it < kStreamIters; ++it) {
-      const int g = base + it * kTraceBlock + tid;
-      bb[it] = make_float4(kInf, kInf, -kInf, -kInf);
-      if (g < a.n) bb[it] = a.bbox[g];
+    for (int it = 0; it < kSlabIters; ++it) {
+      const int sl = sbase + it * kTraceBlock + tid;
+      sb[it] = make_float4(kInf, kInf, -kInf, -kInf);
+      if (sl < nslabs) sb[it] = a.slab_bbox[sl];
     }
-    unsigned long long keep_m[kStreamIters];
+    unsigned long long keep_m[kSlabIters];
     int wcnt = 0;
 #pragma unroll
-    for (int it = 0; it < kStreamIters; ++it) {
-      const bool keep = bb[it].x <= mXhi && bb[it].z >= mXlo && bb[it].y <= mYhi && bb[it].w >= mYlo;
+    for (int it = 0; it < kSlabIters; ++it) {
+      const bool keep = sb[it].x <= mXhi && sb[it].z >= mXlo && sb[it].y <= mYhi && sb[it].w >= mYlo;
       keep_m[it] = __ballot(keep);
       wcnt += __popcll(keep_m[it]);
     }
     if (lane == 0) s_wcnt[par][wave] = wcnt;
+    if (tid == 0) s_n = 0;
     __syncthreads();
-    int off = cnt;
+    int off = 0, scnt = 0;
 #pragma unroll
     for (int w = 0; w < kWavesPerTile; ++w) {
       const int c = s_wcnt[par][w];
       off += (w < wave) ? c : 0;
-      cnt += c;
+      scnt += c;
     }
 #pragma unroll
-    for (int it = 0; it < kStreamIters; ++it) {
+    for (int it = 0; it < kSlabIters; ++it) {
       if ((keep_m[it] >> lane) & 1ull)
-        s_idx[off + __popcll(keep_m[it] & lane_lt)] = base + it * kTraceBlock + tid;
+        s_slab[off + __popcll(keep_m[it] & lane_lt)] = sbase + it * kTraceBlock + tid;
       off += __popcll(keep_m[it]);
     }
-    const bool last = base + kSuper >= a.n;
-    if (cnt + kSuper <= kListCap && !last) continue;
-    __syncthreads();  // the list is complete
+    __syncthreads();
 
-    // ---- every wave: survivors vs its own 8x8 tile, then exact per-ray tests ----
-    if (wave_live) {
-      for (int c = 0; c < cnt; c += kWave) {
-        const int slot = c + lane;
-        const int g = slot < cnt ? s_idx[slot] : -1;
-        float4 wb = make_float4(kInf, kInf, -kInf, -kInf);
-        if (g >= 0) wb = a.bbox[g];
-        const bool pass = wb.x <= wXhi && wb.z >= wXlo && wb.y <= wYhi && wb.w >= wYlo;
-        unsigned long long m = __ballot(pass);
-        if (!m) continue;
-        float4 r0, r1, r2, r3, r4;
-        r0 = r1 = r2 = r3 = r4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (pass) {
-          const float4* rp = reinterpret_cast<const float4*>(a.rec + (size_t)g * kRecFloats);
-          r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = rp[3]; r4 = rp[4];
-        }
-        while (m) {
-          const int b = __builtin_ctzll(m);
-          m &= m - 1;
-          const int gi = __builtin_amdgcn_readlane(g, b);
-          // delta/4 = e_c + g.(x,y) - (x,y) P (x,y)^T about the record's expansion point
-          const float x = X - bcast(r0.x, b);
-          const float y = Y - bcast(r0.y, b);
-          const float e = bcast(r0.z, b) -
-                          ((bcast(r1.y, b) * x + bcast(r1.z, b) * y - bcast(r0.w, b)) * x +
-                           (bcast(r1.w, b) * y - bcast(r1.x, b)) * y);
-          bool hit = e > 0.f && in_img;
-          if (!__any(hit)) continue;
-          const float A = bcast(r2.x, b) + bcast(r2.y, b) * x + bcast(r2.z, b) * y +
-                          (bcast(r2.w, b) * x + bcast(r3.x, b) * y) * x + (bcast(r3.y, b) * y) * y;
-          const float bq = bcast(r3.z, b) + bcast(r3.w, b) * x + bcast(r4.x, b) * y;
-          hit = hit && bq < 0.f;   // the cone half in front of the camera
-          // smaller root of A t^2 + 2 b t + C (gaussian.py:224) in its cancellation-free form
-          // t1 = C / (sqrt(delta/4) - b): C > 0 and b < 0, so nothing is subtracted
-          const float t1 = (bcast(r4.y, b) / (sqrtf(e) - bq)) * dlen;
-          const bool cand = hit && t1 > start && t1 < kInf;  // scene.py:433
-          const unsigned long long kn =
-              cand ? (((unsigned long long)__float_as_uint(t1) << 32) | (unsigned)gi) : ~0ull;
-          if (__any(kn < key[RTGS_MAX_DEPTH - 1])) list_insert(key, wexp, kn, e / A);
+    for (int b0 = 0; b0 < scnt; b0 += kBatch) {
+      // ---- expand a batch of surviving slabs: one wave per slab, one lane per Gaussian.
+      // Slot order in s_idx depends on wave timing, the image does not (see list_insert).
+      const int bend = min(scnt, b0 + kBatch);
+      for (int k = b0 + wave; k < bend; k += kWavesPerTile) {
+        const int g = s_slab[k] * kSlab + lane;
+        float4 gb = make_float4(kInf, kInf, -kInf, -kInf);
+        if (g < a.n) gb = a.bbox[g];
+        const bool keep = gb.x <= mXhi && gb.z >= mXlo && gb.y <= mYhi && gb.w >= mYlo;
+        const unsigned long long m = __ballot(keep);
+        if (m) {
+          int wb = 0;
+          if (lane == 0) wb = atomicAdd(&s_n, __popcll(m));
+          wb = __builtin_amdgcn_readfirstlane(wb);
+          if (keep) s_idx[wb + __popcll(m & lane_lt)] = g;
         }
       }
+      __syncthreads();
+      const int cnt = s_n;
+
+      // ---- every wave: survivors vs its own 8x8 tile, then exact per-ray tests ----
+      if (wave_live) {
+        for (int c = 0; c < cnt; c += kWave) {
+          const int slot = c + lane;
+          const int g = slot < cnt ? s_idx[slot] : -1;
+          float4 wb = make_float4(kInf, kInf, -kInf, -kInf);
+          if (g >= 0) wb = a.bbox[g];
+          const bool pass = wb.x <= wXhi && wb.z >= wXlo && wb.y <= wYhi && wb.w >= wYlo;
+          unsigned long long m = __ballot(pass);
+          if (!m) continue;
+          float4 r0, r1, r2, r3, r4;
+          r0 = r1 = r2 = r3 = r4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (pass) {
+            const float4* rp = reinterpret_cast<const float4*>(a.rec + (size_t)g * kRecFloats);
+            r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = rp[3]; r4 = rp[4];
+          }
+          while (m) {
+            const int b = __builtin_ctzll(m);
+            m &= m - 1;
+            const int gi = __builtin_amdgcn_readlane(g, b);
+            // delta/4 = e_c + g.(x,y) - (x,y) P (x,y)^T about the record's expansion point
+            const float x = X - bcast(r0.x, b);
+            const float y = Y - bcast(r0.y, b);
+            const float e = bcast(r0.z, b) -
+                            ((bcast(r1.y, b) * x + bcast(r1.z, b) * y - bcast(r0.w, b)) * x +
+                             (bcast(r1.w, b) * y - bcast(r1.x, b)) * y);
+            bool hit = e > 0.f && in_img;
+            if (!__any(hit)) continue;
+            const float A = bcast(r2.x, b) + bcast(r2.y, b) * x + bcast(r2.z, b) * y +
+                            (bcast(r2.w, b) * x + bcast(r3.x, b) * y) * x + (bcast(r3.y, b) * y) * y;
+            const float bq = bcast(r3.z, b) + bcast(r3.w, b) * x + bcast(r4.x, b) * y;
+            hit = hit && bq < 0.f;   // the cone half in front of the camera
+            // smaller root of A t^2 + 2 b t + C (gaussian.py:224) in its cancellation-free form
+            // t1 = C / (sqrt(delta/4) - b): C > 0 and b < 0, so nothing is subtracted
+            const float t1 = (bcast(r4.y, b) / (sqrtf(e) - bq)) * dlen;
+            const bool cand = hit && t1 > start && t1 < kInf;  // scene.py:433
+            const unsigned long long kn =
+                cand ? (((unsigned long long)__float_as_uint(t1) << 32) | (unsigned)gi) : ~0ull;
+            if (__any(kn < key[RTGS_MAX_DEPTH - 1])) list_insert(key, wexp, kn, e / A);
+          }
+        }
+      }
+      __syncthreads();  // everyone is done with s_idx / s_n before the next batch refills them
+      if (tid == 0) s_n = 0;
+      __syncthreads();
     }
-    __syncthreads();  // everyone is done reading the list before it is refilled
-    cnt = 0;
   }
 
   // ---- front-to-back compositing of the sorted list (ray_tracer.py:88-104) ----
@@ -448,8 +491,10 @@ extern "C" {
 size_t rtgs_workspace_bytes(int32_t n) {
   if (n <= 0) return 0;
   const size_t nn = ((size_t)n + 63) & ~(size_t)63;
-  return nn * sizeof(float4) + nn * kRecFloats * sizeof(float);
+  return nn * sizeof(float4) + nn * kRecFloats * sizeof(float) + (nn / kSlab) * sizeof(float4);
 }
+
+int32_t rtgs_tile_size(void) { return kTile; }
 
 int32_t rtgs_num_tiles(int32_t width, int32_t height) {
   if (width <= 0 || height <= 0) return 0;
@@ -477,11 +522,12 @@ int rtgs_project(const RtgsScene* scene, const RtgsCamera* cam, void* workspace,
   const size_t nn = ((size_t)scene->n + 63) & ~(size_t)63;
   float4* bbox = static_cast<float4*>(workspace);
   float* rec = reinterpret_cast<float*>(bbox + nn);
+  float4* slab_bbox = reinterpret_cast<float4*>(rec + nn * kRecFloats);
   const FrameCam fc = make_frame_cam(*cam);
   const int block = 256;
   hipLaunchKernelGGL(k_project, dim3((scene->n + block - 1) / block), dim3(block), 0,
                      static_cast<hipStream_t>(stream), scene->n, scene->position, scene->cov_inv6,
-                     fc, bbox, rec);
+                     fc, bbox, slab_bbox, rec);
   return check_launch();
 }
 
@@ -517,6 +563,7 @@ int rtgs_trace(const RtgsScene* scene, const RtgsCamera* cam, const RtgsTracePar
   for (int k = 0; k < 9; ++k) a.rc[k] = (float)fc.rc[k];
   a.bbox = static_cast<const float4*>(workspace);
   a.rec = reinterpret_cast<const float*>(a.bbox + nn);
+  a.slab_bbox = reinterpret_cast<const float4*>(a.rec + nn * kRecFloats);
   a.colop = reinterpret_cast<const float4*>(scene->color_opacity);
   a.sh = scene->sh;
   a.sample = sample_buf;

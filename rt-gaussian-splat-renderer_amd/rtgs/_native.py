@@ -16,7 +16,6 @@ import torch  # noqa: F401  (must precede the CDLL load, see module docstring)
 
 ABI_VERSION = 1
 MAX_DEPTH = 16
-TILE = 32
 RAY_FLOATS = 8
 SH_COEFFS = 15
 
@@ -49,6 +48,7 @@ PROTOTYPES = {
     "rtgs_covariance": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rtgs_generate_rays": (c_int32, [POINTER(RtgsCamera), c_void_p, c_void_p]),
     "rtgs_workspace_bytes": (c_size_t, [c_int32]),
+    "rtgs_tile_size": (c_int32, []),
     "rtgs_num_tiles": (c_int32, [c_int32, c_int32]),
     "rtgs_num_local_tiles": (c_int32, [c_int32, c_int32, c_int32, c_int32]),
     "rtgs_trace": (c_int32, [POINTER(RtgsScene), POINTER(RtgsCamera), POINTER(RtgsTraceParams),
@@ -94,6 +94,11 @@ def lib() -> ctypes.CDLL:
             raise RuntimeError(f"librtgs_hip.so ABI {got} != binding ABI {ABI_VERSION}")
         _lib = handle
     return _lib
+
+
+def tile_size() -> int:
+    """Macro-tile edge (pixels) the library was built with: the unit of sharding."""
+    return lib().rtgs_tile_size()
 
 
 def check(code: int, what: str = "rtgs") -> None:

@@ -1,9 +1,10 @@
 """Tile-parallel rendering: one process per GPU, macro-tiles interleaved over ranks, RCCL gather.
 
 The reference is single-process / single-device (no collective anywhere).  Pixels
-are independent, so the frame shards naturally: the 32x32 macro-tiles are dealt round-robin
+are independent, so the frame shards naturally: the T x T macro-tiles (T = rtgs_tile_size())
+are dealt round-robin
 (tile t -> rank t % world), every rank holds the whole scene (one broadcast at load, Gaussians
-are replicated) and renders its tiles into a compact [tiles_per_rank, 32, 32, 3] buffer, and ONE
+are replicated) and renders its tiles into a compact [tiles_per_rank, T, T, 3] buffer, and ONE
 exchange step -- a ``torch.distributed`` gather (backend "nccl" == RCCL over xGMI) of
 W*H*12/world bytes per rank -- lands the shards on the destination rank, where ``rtgs_untile``
 de-interleaves them into the (W, H, 3) framebuffer.  Frames are double-buffered: the gather of
@@ -16,7 +17,7 @@ import torch
 import torch.distributed as dist
 
 
-def tiles_of(width: int, height: int, tile: int = 32) -> int:
+def tiles_of(width: int, height: int, tile: int) -> int:
     return ((width + tile - 1) // tile) * ((height + tile - 1) // tile)
 
 
@@ -35,6 +36,7 @@ class HipBackend:
         self.depth, self.t_cutoff = int(depth), float(t_cutoff)
         self.device = nat.device()
         self.width, self.height = camera.buf_size.x, camera.buf_size.y
+        self.tile = nat.tile_size()
         need = nat.lib().rtgs_workspace_bytes(scene.num_gaussians)
         self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
 
@@ -65,13 +67,12 @@ class HipBackend:
 class TileParallelRenderer:
     """Renders whole frames on `world` ranks; the image lands in ``framebuffer`` on rank `dst`."""
 
-    TILE = 32
-
     def __init__(self, scene=None, camera=None, depth: int = 16, rank: int = 0, world: int = 1,
                  t_cutoff: float = 0.0, dst: int = 0, group=None, backend=None):
         self.backend = backend if backend is not None else HipBackend(scene, camera, depth, t_cutoff)
         self.rank, self.world, self.dst, self.group = int(rank), int(world), int(dst), group
         b = self.backend
+        self.TILE = int(b.tile)
         self.total_tiles = tiles_of(b.width, b.height, self.TILE)
         self.tiles_per_rank = (self.total_tiles + self.world - 1) // self.world
         self.local_tiles = local_tile_count(self.total_tiles, self.rank, self.world)

@@ -77,6 +77,27 @@ def read_ply(path) -> dict:
     raise ValueError(f"{path}: unsupported PLY format {fmt}")
 
 
+def morton_order(position: torch.Tensor) -> torch.Tensor:
+    """Stable argsort of the 30-bit Morton codes of the positions (device, torch).
+
+    The render kernels stream Gaussians in slabs of 64 consecutive records and cull whole slabs
+    by their union screen bound, so consecutive records should be spatially close.  This is the
+    (camera-independent, load-time) stand-in for the reference's BVH build (scene.py:162-404).
+    The sort is stable: exact duplicates keep their original relative order."""
+    p = torch.nan_to_num(position.detach().to(torch.float64), nan=0.0, posinf=0.0, neginf=0.0)
+    lo, hi = p.amin(dim=0), p.amax(dim=0)
+    q = ((p - lo) / (hi - lo).clamp_min(1e-300) * 1023.0).round().clamp(0, 1023).to(torch.int64)
+
+    def spread(v):
+        v = (v | (v << 16)) & 0x030000FF
+        v = (v | (v << 8)) & 0x0300F00F
+        v = (v | (v << 4)) & 0x030C30C3
+        return (v | (v << 2)) & 0x09249249
+
+    code = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+    return torch.argsort(code, stable=True)
+
+
 class Scene:
     """scene.py:64-87.  max_num_node / balance_weight / leaf_prim are accepted for signature
     compatibility; they parameterise the reference's BVH, which this path does not build."""
@@ -89,6 +110,8 @@ class Scene:
         self.gaussian_field = None  # scene.py:83 allocates a shape-() field; filled by load
         self.num_gaussians = 0
         self.position = self.cov_inv6 = self.color_opacity = self.sh = None
+        self.order = None           # stream slot -> index into gaussian_field
+        self.sort_spatially = True  # Morton-order the streamed copies (see morton_order)
 
     # ---- construction ------------------------------------------------------------------
     @classmethod
@@ -124,21 +147,31 @@ class Scene:
     def commit(self, has_sh: bool | None = None) -> None:
         """(Re)build the device buffers the kernels stream from ``gaussian_field``:
         quaternion+scale -> inverse covariance (gaussian.py:86-102 via ``rtgs_covariance``),
-        colour and opacity packed to 16 B."""
+        colour and opacity packed to 16 B.  The streamed copies are stored in Morton order
+        (``self.order`` maps a stream slot back to the ``gaussian_field`` index)."""
         f = self.gaussian_field
         n = f.n
         if n <= 0:
             raise ValueError("scene has no Gaussians")
         self.num_gaussians = n
-        self.position = f.position.contiguous()
-        self.cov_inv6 = torch.empty((n, 6), dtype=torch.float32, device=f.position.device)
-        nat.check(nat.lib().rtgs_covariance(n, nat.ptr(f.rotation.contiguous()),
-                                            nat.ptr(f.scale.contiguous()), None,
+        dev = f.position.device
+        if self.sort_spatially and n > 64:
+            self.order = morton_order(f.position)
+        else:
+            self.order = torch.arange(n, device=dev)
+        o = self.order
+        self.position = f.position[o].contiguous()
+        self.cov_inv6 = torch.empty((n, 6), dtype=torch.float32, device=dev)
+        # keep the permuted temporaries alive across the launch: a freed block would be handed
+        # straight to the next temporary by the caching allocator
+        rot_s, scale_s = f.rotation[o].contiguous(), f.scale[o].contiguous()
+        nat.check(nat.lib().rtgs_covariance(n, nat.ptr(rot_s), nat.ptr(scale_s), None,
                                             nat.ptr(self.cov_inv6), nat.stream()), "rtgs_covariance")
-        self.color_opacity = torch.cat([f.color, f.opacity[:, None]], dim=1).contiguous()
+        del rot_s, scale_s
+        self.color_opacity = torch.cat([f.color, f.opacity[:, None]], dim=1)[o].contiguous()
         if has_sh is None:
             has_sh = bool(torch.any(f.sh != 0).item())
-        self.sh = f.sh.reshape(n, 45).contiguous() if has_sh else None
+        self.sh = f.sh.reshape(n, 45)[o].contiguous() if has_sh else None
 
     def load_file(self, path: pathlib.Path, scale: float = 1):
         """Load an INRIA-3DGS PLY (scene.py:89-131): wxyz -> xyzw (:103), normalised
@@ -193,6 +226,8 @@ class Scene:
             scene = self.native()
             nat.check(nat.lib().rtgs_closest_hit(scene, n, nat.ptr(data), nat.ptr(idx), nat.ptr(t),
                                                  nat.stream()), "rtgs_closest_hit")
+            # stream slot -> gaussian_field index
+            idx = torch.where(idx >= 0, self.order[idx.clamp_min(0).long()].to(torch.int32), idx)
         return idx, t
 
     def hit(self, ray: Ray) -> SceneHit:

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     from rtgs import _native as nat
     lib = nat.lib()
     names = header_functions()
-    assert len(names) >= 17
+    assert len(names) >= 18
     for name in names:
         assert hasattr(lib, name), f"{name} declared in include/rtgs_hip.h but not exported"
     assert sorted(nat.PROTOTYPES) == names, "ctypes prototypes and header disagree"
@@ -40,13 +40,15 @@ def test_pure_host_entry_points():
         assert len(lib.rtgs_strerror(code)) > 0
     assert lib.rtgs_workspace_bytes(0) == 0 and lib.rtgs_workspace_bytes(-5) == 0
     assert lib.rtgs_workspace_bytes(100_000) >= 100_000 * 96
-    assert lib.rtgs_num_tiles(1920, 1080) == 60 * 34
+    t = lib.rtgs_tile_size()
+    assert t in (8, 16, 32) and t == nat.tile_size()
+    assert lib.rtgs_num_tiles(1920, 1080) == -(-1920 // t) * -(-1080 // t)
     assert lib.rtgs_num_tiles(1, 1) == 1 and lib.rtgs_num_tiles(0, 5) == 0
     total = lib.rtgs_num_tiles(1920, 1080)
     assert sum(lib.rtgs_num_local_tiles(1920, 1080, r, 8) for r in range(8)) == total
     assert lib.rtgs_num_local_tiles(1920, 1080, 0, 1) == total
-    assert lib.rtgs_num_local_tiles(32, 32, 3, 8) == 0      # more ranks than tiles
-    assert lib.rtgs_num_local_tiles(32, 32, 0, 0) == 0
+    assert lib.rtgs_num_local_tiles(t, t, 3, 8) == 0        # more ranks than tiles
+    assert lib.rtgs_num_local_tiles(t, t, 0, 0) == 0
 
 
 def test_argument_validation_needs_no_gpu():

@@ -179,7 +179,8 @@ def test_sharded_render_equals_whole_frame(world):
     w, h = cam["width"], cam["height"]
     total = lib.rtgs_num_tiles(w, h)
     per = (total + world - 1) // world
-    compact = torch.zeros((world, per, 32, 32, 3), device=whole.device)
+    T = nat.tile_size()
+    compact = torch.zeros((world, per, T, T, 3), device=whole.device)
     for r in range(world):
         tracer.trace(depth, flags=nat.TRACE_COMPACT, tile_first=r, tile_step=world, sample_buf=compact[r])
     image = torch.full_like(whole, -1.0)

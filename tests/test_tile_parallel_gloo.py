@@ -15,7 +15,7 @@ import torch.multiprocessing as mp
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-W, H, TILE = 80, 72, 32     # 3 x 3 macro-tiles, ragged right/top edges
+W, H, TILE = 80, 72, 32     # 3 x 3 stand-in macro-tiles, ragged right/top edges
 
 
 def _oracle_image():
@@ -35,7 +35,7 @@ class OracleBackend:
     so that a stale or swapped double buffer would be caught."""
 
     def __init__(self, image):
-        self.width, self.height, self.image, self.frame = W, H, image, 0
+        self.width, self.height, self.tile, self.image, self.frame = W, H, TILE, image, 0
 
     def alloc(self, *shape):
         return torch.zeros(shape, dtype=torch.float32)
@@ -72,7 +72,7 @@ def _worker(rank, world, port, frames, q):
         image = _oracle_image()
         from rtgs.parallel import TileParallelRenderer, local_tile_count, tiles_of
         r = TileParallelRenderer(backend=OracleBackend(image), rank=rank, world=world)
-        assert r.total_tiles == tiles_of(W, H) == 9
+        assert r.total_tiles == tiles_of(W, H, TILE) == 9
         assert r.local_tiles == local_tile_count(9, rank, world)
         for _ in range(frames):
             r.render_frame()
@@ -111,7 +111,7 @@ def test_tile_deal_covers_every_tile_once():
     from rtgs.parallel import local_tile_count, tiles_of
     lib = nat.lib()
     for (w, h) in [(1920, 1080), (3840, 2160), (800, 600), (33, 1)]:
-        total = tiles_of(w, h)
+        total = tiles_of(w, h, nat.tile_size())
         assert total == lib.rtgs_num_tiles(w, h)
         for world in (1, 2, 3, 8):
             counts = [local_tile_count(total, r, world) for r in range(world)]
