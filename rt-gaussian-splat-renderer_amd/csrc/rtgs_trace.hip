@@ -38,12 +38,26 @@
 namespace rtgs {
 namespace {
 
+// Tuning switches; defaults = the fastest measured on MI355X (c3, tools/variants.sh, round 1):
+//   REC_MODE 0 / 1 / 2 = 0.426 / 0.377 / 0.406 ms, FILL_SKIP 1 = 2x slower (branch chain),
+//   FAST_DIV 0 = +8 %.
+#ifndef RTGS_REC_MODE
+#define RTGS_REC_MODE 1   // 0: record held by a lane, broadcast with v_readlane; 1: scalar loads;
+#endif                    // 2: scalar loads prefetched one candidate ahead
+#ifndef RTGS_FILL_SKIP
+#define RTGS_FILL_SKIP 0  // stop the insertion bubble at the longest list of the wave
+#endif
+#ifndef RTGS_FAST_DIV
+#define RTGS_FAST_DIV 1   // v_rcp_f32 / v_sqrt_f32 (1 ulp) instead of IEEE division / sqrt
+#endif
+
 constexpr int kSlab = 64;                                 // Gaussians per slab = one wave
-constexpr int kSlabIters = 2048 / kTraceBlock;            // slab bounds in flight per thread
-constexpr int kSlabChunk = kSlabIters * kTraceBlock;      // slabs scanned per barrier (2048)
-constexpr int kSlabCap = kSlabChunk;                      // LDS list of surviving slabs
-constexpr int kListCap = 2048;                            // LDS list of surviving Gaussians
+constexpr int kSlabIters = 4;                             // slab bounds in flight per thread
+constexpr int kSlabStep = kSlabIters * kTraceBlock;       // slabs scanned per barrier
+constexpr int kSlabCap = 2048;                            // LDS list of surviving slabs
+constexpr int kListCap = 1024;                            // LDS list of surviving Gaussians
 constexpr int kBatch = kListCap / kSlab;                  // slabs expanded per batch
+static_assert(kSlabCap >= 2 * kSlabStep || kSlabCap >= kSlabStep + 64, "slab list too small");
 
 struct TraceArgs {
   int32_t n;
@@ -55,11 +69,6 @@ struct TraceArgs {
   uint32_t flags;
   float inv_fx, inv_fy;
   float rc[9];  // camera rotation, for the SH direction only
-  const float4* __restrict__ bbox;
-  const float4* __restrict__ slab_bbox;
-  const float* __restrict__ rec;
-  const float4* __restrict__ colop;
-  const float* __restrict__ sh;
   float* sample;
   float* att;
   float* start;
@@ -198,18 +207,36 @@ __global__ __launch_bounds__(256) void k_project(int32_t n, const float* __restr
 // trace
 // ------------------------------------------------------------------------------------
 
+struct Rgb { float r, g, b; };
+struct Rec5 { float4 q[5]; };
+
 __device__ __forceinline__ float bcast(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ float4 bcast4(const float4& v, int lane) {
+  return make_float4(bcast(v.x, lane), bcast(v.y, lane), bcast(v.z, lane), bcast(v.w, lane));
+}
+__device__ __forceinline__ Rec5 load_rec(const float4* __restrict__ rec, int gi) {
+  const float4* rp = rec + (size_t)gi * (kRecFloats / 4);
+  Rec5 r;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) r.q[k] = rp[k];
+  return r;
 }
 
 // Sorted insert into the per-lane list of the RTGS_MAX_DEPTH smallest keys.  A key is
 // (t1 bits << 32 | Gaussian index): t1 > 0, so unsigned order == (t1, index) lexicographic
 // order, which makes the result independent of the order Gaussians arrive in.
+// `fill` (wave-uniform) bounds the number of valid entries of every lane's list: levels beyond
+// it hold only empty keys, so the bubble stops there.
 __device__ __forceinline__ void list_insert(unsigned long long (&key)[RTGS_MAX_DEPTH],
                                             float (&wexp)[RTGS_MAX_DEPTH],
-                                            unsigned long long kn, float wn) {
+                                            unsigned long long kn, float wn, int fill) {
 #pragma unroll
   for (int k = 0; k < RTGS_MAX_DEPTH; ++k) {
+#if RTGS_FILL_SKIP
+    if (k > fill) break;  // wave-uniform
+#endif
     const bool lt = kn < key[k];
     const unsigned long long kk = key[k];
     const float ww = wexp[k];
@@ -243,8 +270,14 @@ __device__ __forceinline__ void sh_basis(float x, float y, float z, float (&Y)[R
 }
 
 template <bool kHasSh>
-__global__ __launch_bounds__(kTraceBlock, 4) void k_trace(const TraceArgs a) {
+__global__ __launch_bounds__(kTraceBlock, 4) void k_trace(const TraceArgs a,
+                                                          const float4* __restrict__ bbox,
+                                                          const float4* __restrict__ slab_bbox,
+                                                          const float4* __restrict__ rec,
+                                                          const float4* __restrict__ colop,
+                                                          const float* __restrict__ sh) {
   __shared__ int s_slab[kSlabCap];
+  __shared__ float4 s_bb[kListCap];
   __shared__ int s_idx[kListCap];
   __shared__ int s_wcnt[2][kWavesPerTile];
   __shared__ int s_n;
@@ -289,20 +322,24 @@ __global__ __launch_bounds__(kTraceBlock, 4) void k_trace(const TraceArgs a) {
   constexpr unsigned long long kEmpty = 0x7F800000FFFFFFFFull;  // (+inf, -1)
 #pragma unroll
   for (int k = 0; k < RTGS_MAX_DEPTH; ++k) { key[k] = kEmpty; wexp[k] = 0.f; }
+  int nvalid = 0;   // entries in this lane's list
+  int fill = 0;     // wave-uniform max of nvalid
 
   const unsigned long long lane_lt = (1ull << lane) - 1ull;
   const int nslabs = (a.n + kSlab - 1) / kSlab;
+  if (tid == 0) s_n = 0;
 
-  for (int sbase = 0, par = 0; sbase < nslabs; sbase += kSlabChunk, par ^= 1) {
-    // ---- scan a chunk of slab bounds; keep the slabs that touch the macro-tile.  The list is
-    // built without atomics: every wave publishes its count, one barrier later every thread
-    // derives the same offsets (s_wcnt is double-buffered by chunk parity).
+  int scnt = 0;  // surviving slabs listed so far: identical in every thread
+  for (int sbase = 0, par = 0; sbase < nslabs; sbase += kSlabStep, par ^= 1) {
+    // ---- scan slab bounds; keep the slabs that touch the macro-tile.  The list is built
+    // without atomics: every wave publishes its count, one barrier later every thread derives
+    // the same offsets (s_wcnt is double-buffered by step parity).
     float4 sb[kSlabIters];
 #pragma unroll
     for (int it = 0; it < kSlabIters; ++it) {
       const int sl = sbase + it * kTraceBlock + tid;
       sb[it] = make_float4(kInf, kInf, -kInf, -kInf);
-      if (sl < nslabs) sb[it] = a.slab_bbox[sl];
+      if (sl < nslabs) sb[it] = slab_bbox[sl];
     }
     unsigned long long keep_m[kSlabIters];
     int wcnt = 0;
@@ -313,9 +350,8 @@ __global__ __launch_bounds__(kTraceBlock, 4) void k_trace(const TraceArgs a) {
       wcnt += __popcll(keep_m[it]);
     }
     if (lane == 0) s_wcnt[par][wave] = wcnt;
-    if (tid == 0) s_n = 0;
     __syncthreads();
-    int off = 0, scnt = 0;
+    int off = scnt;
 #pragma unroll
     for (int w = 0; w < kWavesPerTile; ++w) {
       const int c = s_wcnt[par][w];
@@ -328,23 +364,29 @@ __global__ __launch_bounds__(kTraceBlock, 4) void k_trace(const TraceArgs a) {
         s_slab[off + __popcll(keep_m[it] & lane_lt)] = sbase + it * kTraceBlock + tid;
       off += __popcll(keep_m[it]);
     }
-    __syncthreads();
+    const bool last = sbase + kSlabStep >= nslabs;
+    if (scnt + kSlabStep <= kSlabCap && !last) continue;
+    __syncthreads();  // the slab list is complete
 
     for (int b0 = 0; b0 < scnt; b0 += kBatch) {
       // ---- expand a batch of surviving slabs: one wave per slab, one lane per Gaussian.
-      // Slot order in s_idx depends on wave timing, the image does not (see list_insert).
+      // Slot order in the list depends on wave timing, the image does not (see list_insert).
       const int bend = min(scnt, b0 + kBatch);
       for (int k = b0 + wave; k < bend; k += kWavesPerTile) {
         const int g = s_slab[k] * kSlab + lane;
         float4 gb = make_float4(kInf, kInf, -kInf, -kInf);
-        if (g < a.n) gb = a.bbox[g];
+        if (g < a.n) gb = bbox[g];
         const bool keep = gb.x <= mXhi && gb.z >= mXlo && gb.y <= mYhi && gb.w >= mYlo;
         const unsigned long long m = __ballot(keep);
         if (m) {
           int wb = 0;
           if (lane == 0) wb = atomicAdd(&s_n, __popcll(m));
           wb = __builtin_amdgcn_readfirstlane(wb);
-          if (keep) s_idx[wb + __popcll(m & lane_lt)] = g;
+          if (keep) {
+            const int slot = wb + __popcll(m & lane_lt);
+            s_idx[slot] = g;
+            s_bb[slot] = gb;
+          }
         }
       }
       __syncthreads();
@@ -354,48 +396,85 @@ __global__ __launch_bounds__(kTraceBlock, 4) void k_trace(const TraceArgs a) {
       if (wave_live) {
         for (int c = 0; c < cnt; c += kWave) {
           const int slot = c + lane;
-          const int g = slot < cnt ? s_idx[slot] : -1;
+          int g = -1;
           float4 wb = make_float4(kInf, kInf, -kInf, -kInf);
-          if (g >= 0) wb = a.bbox[g];
+          if (slot < cnt) { g = s_idx[slot]; wb = s_bb[slot]; }
           const bool pass = wb.x <= wXhi && wb.z >= wXlo && wb.y <= wYhi && wb.w >= wYlo;
           unsigned long long m = __ballot(pass);
-          if (!m) continue;
+#if RTGS_REC_MODE == 0
           float4 r0, r1, r2, r3, r4;
           r0 = r1 = r2 = r3 = r4 = make_float4(0.f, 0.f, 0.f, 0.f);
           if (pass) {
-            const float4* rp = reinterpret_cast<const float4*>(a.rec + (size_t)g * kRecFloats);
+            const float4* rp = rec + (size_t)g * (kRecFloats / 4);
             r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = rp[3]; r4 = rp[4];
           }
+#elif RTGS_REC_MODE == 2
+          Rec5 nxt;
+          int gnext = 0;
+          if (m) {
+            gnext = __builtin_amdgcn_readlane(g, __builtin_ctzll(m));
+            nxt = load_rec(rec, gnext);
+          }
+#endif
           while (m) {
             const int b = __builtin_ctzll(m);
             m &= m - 1;
+#if RTGS_REC_MODE == 0
             const int gi = __builtin_amdgcn_readlane(g, b);
+            const float4 q0 = bcast4(r0, b), q1 = bcast4(r1, b), q2 = bcast4(r2, b),
+                         q3 = bcast4(r3, b), q4 = bcast4(r4, b);
+#elif RTGS_REC_MODE == 1
+            // the record's address is wave-uniform: scalar loads, operands straight from SGPRs
+            const int gi = __builtin_amdgcn_readlane(g, b);
+            const float4* rp = rec + (size_t)gi * (kRecFloats / 4);
+            const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3], q4 = rp[4];
+#else
+            const int gi = gnext;
+            const Rec5 cur = nxt;
+            if (m) {
+              gnext = __builtin_amdgcn_readlane(g, __builtin_ctzll(m));
+              nxt = load_rec(rec, gnext);
+            }
+            const float4 q0 = cur.q[0], q1 = cur.q[1], q2 = cur.q[2], q3 = cur.q[3], q4 = cur.q[4];
+#endif
             // delta/4 = e_c + g.(x,y) - (x,y) P (x,y)^T about the record's expansion point
-            const float x = X - bcast(r0.x, b);
-            const float y = Y - bcast(r0.y, b);
-            const float e = bcast(r0.z, b) -
-                            ((bcast(r1.y, b) * x + bcast(r1.z, b) * y - bcast(r0.w, b)) * x +
-                             (bcast(r1.w, b) * y - bcast(r1.x, b)) * y);
+            const float x = X - q0.x;
+            const float y = Y - q0.y;
+            const float e = q0.z - ((q1.y * x + q1.z * y - q0.w) * x + (q1.w * y - q1.x) * y);
             bool hit = e > 0.f && in_img;
             if (!__any(hit)) continue;
-            const float A = bcast(r2.x, b) + bcast(r2.y, b) * x + bcast(r2.z, b) * y +
-                            (bcast(r2.w, b) * x + bcast(r3.x, b) * y) * x + (bcast(r3.y, b) * y) * y;
-            const float bq = bcast(r3.z, b) + bcast(r3.w, b) * x + bcast(r4.x, b) * y;
+            const float A = q2.x + q2.y * x + q2.z * y + (q2.w * x + q3.x * y) * x + (q3.y * y) * y;
+            const float bq = q3.z + q3.w * x + q4.x * y;
             hit = hit && bq < 0.f;   // the cone half in front of the camera
             // smaller root of A t^2 + 2 b t + C (gaussian.py:224) in its cancellation-free form
-            // t1 = C / (sqrt(delta/4) - b): C > 0 and b < 0, so nothing is subtracted
-            const float t1 = (bcast(r4.y, b) / (sqrtf(e) - bq)) * dlen;
+            // t1 = C / (sqrt(delta/4) - b): C > 0 and b < 0, so nothing is subtracted.
+            // v_sqrt_f32 / v_rcp_f32 are 1 ulp: far inside the 1e-4 pixel tolerance.
+#if RTGS_FAST_DIV
+            const float t1 = q4.y * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(e) - bq) * dlen;
+#else
+            const float t1 = (q4.y / (sqrtf(e) - bq)) * dlen;
+#endif
             const bool cand = hit && t1 > start && t1 < kInf;  // scene.py:433
             const unsigned long long kn =
                 cand ? (((unsigned long long)__float_as_uint(t1) << 32) | (unsigned)gi) : ~0ull;
-            if (__any(kn < key[RTGS_MAX_DEPTH - 1])) list_insert(key, wexp, kn, e / A);
+            const bool ins = kn < key[RTGS_MAX_DEPTH - 1];
+            if (__any(ins)) {
+#if RTGS_FAST_DIV
+              list_insert(key, wexp, kn, e * __builtin_amdgcn_rcpf(A), fill);
+#else
+              list_insert(key, wexp, kn, e / A, fill);
+#endif
+              if (__any(ins && nvalid == fill)) fill = min(fill + 1, RTGS_MAX_DEPTH - 1);
+              nvalid += (ins && nvalid < RTGS_MAX_DEPTH) ? 1 : 0;
+            }
           }
         }
       }
-      __syncthreads();  // everyone is done with s_idx / s_n before the next batch refills them
+      __syncthreads();  // everyone is done with the list before the next batch refills it
       if (tid == 0) s_n = 0;
       __syncthreads();
     }
+    scnt = 0;
   }
 
   // ---- front-to-back compositing of the sorted list (ray_tracer.py:88-104) ----
@@ -427,10 +506,10 @@ __global__ __launch_bounds__(kTraceBlock, 4) void k_trace(const TraceArgs a) {
       prev_tbits = tbits;
       const unsigned gi = (unsigned)(key[k] & 0xFFFFFFFFull);
       float4 co = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (valid) co = a.colop[gi];
+      if (valid) co = colop[gi];
       if (kHasSh) {
         if (valid) {
-          const float* s = a.sh + (size_t)gi * (RTGS_SH_COEFFS * 3);
+          const float* s = sh + (size_t)gi * (RTGS_SH_COEFFS * 3);
 #pragma unroll
           for (int q = 0; q < RTGS_SH_COEFFS; ++q) {
             co.x += Ysh[q] * s[3 * q + 0];
@@ -452,11 +531,14 @@ __global__ __launch_bounds__(kTraceBlock, 4) void k_trace(const TraceArgs a) {
 
   if (a.flags & RTGS_TRACE_COMPACT) {
     float* o = a.sample + ((size_t)blockIdx.x * kTile * kTile + (size_t)(pi - mi0) * kTile + (pj - mj0)) * 3;
-    o[0] = L0; o[1] = L1; o[2] = L2;
+    *reinterpret_cast<Rgb*>(o) = Rgb{L0, L1, L2};   // one 12-B store per lane
   } else if (in_img) {
     float* o = a.sample + pix * 3;
-    if (a.flags & RTGS_TRACE_ACCUMULATE) { L0 += o[0]; L1 += o[1]; L2 += o[2]; }
-    o[0] = L0; o[1] = L1; o[2] = L2;
+    if (a.flags & RTGS_TRACE_ACCUMULATE) {
+      const Rgb old = *reinterpret_cast<const Rgb*>(o);
+      L0 += old.r; L1 += old.g; L2 += old.b;
+    }
+    *reinterpret_cast<Rgb*>(o) = Rgb{L0, L1, L2};
   }
   if (in_img) {
     if (a.att) a.att[pix] = T;
@@ -561,20 +643,21 @@ int rtgs_trace(const RtgsScene* scene, const RtgsCamera* cam, const RtgsTracePar
   a.inv_fx = (float)fc.inv_fx;
   a.inv_fy = (float)fc.inv_fy;
   for (int k = 0; k < 9; ++k) a.rc[k] = (float)fc.rc[k];
-  a.bbox = static_cast<const float4*>(workspace);
-  a.rec = reinterpret_cast<const float*>(a.bbox + nn);
-  a.slab_bbox = reinterpret_cast<const float4*>(a.rec + nn * kRecFloats);
-  a.colop = reinterpret_cast<const float4*>(scene->color_opacity);
-  a.sh = scene->sh;
+  const float4* bbox = static_cast<const float4*>(workspace);
+  const float4* rec = bbox + nn;
+  const float4* slab_bbox = rec + nn * (kRecFloats / 4);
+  const float4* colop = reinterpret_cast<const float4*>(scene->color_opacity);
   a.sample = sample_buf;
   a.att = attenuation_buf;
   a.start = ray_start;
   a.start_stride = ray_start ? ray_start_stride : 1;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (scene->sh)
-    hipLaunchKernelGGL(k_trace<true>, dim3(local), dim3(kTraceBlock), 0, s, a);
+    hipLaunchKernelGGL(k_trace<true>, dim3(local), dim3(kTraceBlock), 0, s, a, bbox, slab_bbox, rec, colop,
+                       scene->sh);
   else
-    hipLaunchKernelGGL(k_trace<false>, dim3(local), dim3(kTraceBlock), 0, s, a);
+    hipLaunchKernelGGL(k_trace<false>, dim3(local), dim3(kTraceBlock), 0, s, a, bbox, slab_bbox, rec, colop,
+                       static_cast<const float*>(nullptr));
   return check_launch();
 }
 

@@ -23,7 +23,8 @@ TRACE_RESUME = 1
 TRACE_ACCUMULATE = 2
 TRACE_COMPACT = 4
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "librtgs_hip.so")
+LIB_PATH = os.environ.get("RTGS_HIP_LIB") or os.path.join(
+    os.path.dirname(os.path.abspath(__file__)), "_lib", "librtgs_hip.so")
 
 
 class RtgsScene(Structure):
