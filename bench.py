@@ -66,11 +66,25 @@ def cpu_baseline(cfg, arrays, cam, n_rays):
             t0 = time.perf_counter()
             c_oracle.render(arrays, cam, cfg.depth, pix2)
             dt2 = time.perf_counter() - t0
-            out["c_openmp"] = {"value": n2 / dt2 / 1e6, "unit": "Mrays/s", "cores": os.cpu_count(),
+            out["c_openmp"] = {"value": n2 / dt2 / 1e6, "unit": "Mrays/s",
+                               "cores": len(os.sched_getaffinity(0)),
                                "sample": f"{n2} seeded random pixels, C fp64 one-pass, {dt2:.1f} s"}
     except Exception as exc:  # the optional line must never break the bench
         out["c_openmp"] = {"error": repr(exc)}
     return out
+
+
+def profiled_traffic(cfg_name, world):
+    """HBM bytes per k_trace launch from the committed rocprofv3 PMC summary of the same
+    command (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE; separate --pmc passes).
+    Counters cannot be read from inside the bench, so this is the profiled value, or None."""
+    path = os.path.join(ROOT, "profiles", f"r01_{cfg_name}_summary.json")
+    if world != 1 or not os.path.exists(path):
+        return None, None
+    with open(path) as f:
+        summary = json.load(f)
+    t = summary.get("k_trace_hbm_bytes_per_launch")
+    return (t["traffic_upper"], os.path.relpath(path, ROOT)) if t else (None, None)
 
 
 def main():
@@ -146,6 +160,7 @@ def main():
         bpr = synthetic.bytes_per_ray(cfg.n, cfg.sh, cfg.depth)
         local_rays = renderer.local_tiles * nat.tile_size() ** 2
         achieved = bpr * min(local_rays, cfg.rays) / (trace_ms * 1e-3) / 1e9  # GB/s, this rank's launch
+        traffic, traffic_src = profiled_traffic(cfg.name, world)
         line = {
             "metric": "Mrays/s at 1920x1080, 100k Gaussians; achieved HBM GB/s vs peak",
             "value": mrays, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
@@ -158,7 +173,9 @@ def main():
                        "parallelism": f"tile-parallel x{world}" + (" + RCCL gather" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": "k_trace", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel_ms": trace_ms, "project_ms": project_ms,
+                         "traffic": traffic, "traffic_unit": "bytes per k_trace launch",
+                         "traffic_source": traffic_src, "kernel_ms": trace_ms,
+                         "project_ms": project_ms,
                          "algorithmic_bytes_per_ray": bpr,
                          "note": "achieved = SURVEY 8(d) streamed bytes/ray x rays per launch / "
                                  "k_trace time; screen-space culling skips most of that stream, "
