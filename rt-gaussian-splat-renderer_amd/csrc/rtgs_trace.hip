@@ -40,12 +40,18 @@ namespace {
 
 // Tuning switches; defaults = the fastest measured on MI355X (c3, tools/variants.sh, round 1):
 //   REC_MODE 0 / 1 / 2 = 0.426 / 0.377 / 0.406 ms, FILL_SKIP 1 = 2x slower (branch chain),
-//   FAST_DIV 0 = +8 %.
+//   FAST_DIV 0 = +8 %, INSERT 0 / 1 = 0.374 / 0.336 ms, WAVES_PER_SIMD 5 spills (0.362 ms).
 #ifndef RTGS_REC_MODE
 #define RTGS_REC_MODE 1   // 0: record held by a lane, broadcast with v_readlane; 1: scalar loads;
 #endif                    // 2: scalar loads prefetched one candidate ahead
 #ifndef RTGS_FILL_SKIP
 #define RTGS_FILL_SKIP 0  // stop the insertion bubble at the longest list of the wave
+#endif
+#ifndef RTGS_INSERT
+#define RTGS_INSERT 1     // 0: compare/select bubble on 64-bit (t1,index) keys (7 VALU/level);
+#endif                    // 1: v_cmpx + v_swap_b32 under EXEC on 32-bit t1 keys (4 VALU/level)
+#ifndef RTGS_WAVES_PER_SIMD
+#define RTGS_WAVES_PER_SIMD 4   // __launch_bounds__ second argument: caps VGPRs at 512/this
 #endif
 #ifndef RTGS_FAST_DIV
 #define RTGS_FAST_DIV 1   // v_rcp_f32 / v_sqrt_f32 (1 ulp) instead of IEEE division / sqrt
@@ -57,6 +63,8 @@ constexpr int kSlabStep = kSlabIters * kTraceBlock;       // slabs scanned per b
 constexpr int kSlabCap = 2048;                            // LDS list of surviving slabs
 constexpr int kListCap = 1024;                            // LDS list of surviving Gaussians
 constexpr int kBatch = kListCap / kSlab;                  // slabs expanded per batch
+constexpr int kSlabsPerWave = kBatch / kWavesPerTile;     // slabs one wave expands per batch
+static_assert(kBatch % kWavesPerTile == 0, "batch must split evenly over the waves");
 static_assert(kSlabCap >= 2 * kSlabStep || kSlabCap >= kSlabStep + 64, "slab list too small");
 
 struct TraceArgs {
@@ -247,6 +255,28 @@ __device__ __forceinline__ void list_insert(unsigned long long (&key)[RTGS_MAX_D
   }
 }
 
+// The same bubble with the hardware's conditional swap: v_cmpx narrows EXEC to the lanes whose
+// carried key is smaller, three v_swap_b32 exchange (t1, index, exponent) in those lanes only,
+// and EXEC is restored.  4 VALU + 1 SALU per level.  Keys are the t1 bits alone; equal t1 keep
+// their arrival order, which k_trace makes deterministic (stream order).
+__device__ __forceinline__ void list_insert_swap(unsigned (&kt)[RTGS_MAX_DEPTH], unsigned (&ki)[RTGS_MAX_DEPTH],
+                                                 float (&kw)[RTGS_MAX_DEPTH], unsigned tn, unsigned in,
+                                                 float wn) {
+  const unsigned long long ex = __builtin_amdgcn_read_exec();
+#pragma unroll
+  for (int k = 0; k < RTGS_MAX_DEPTH; ++k) {
+    asm volatile(
+        "v_cmpx_lt_u32_e32 vcc, %0, %3\n\t"
+        "v_swap_b32 %0, %3\n\t"
+        "v_swap_b32 %1, %4\n\t"
+        "v_swap_b32 %2, %5\n\t"
+        "s_mov_b64 exec, %6"
+        : "+v"(tn), "+v"(in), "+v"(wn), "+v"(kt[k]), "+v"(ki[k]), "+v"(kw[k])
+        : "s"(ex)
+        : "vcc");
+  }
+}
+
 // gaussian.py:149-163, including the y_33 quirk (5 z^2 - 3 z).
 __device__ __forceinline__ void sh_basis(float x, float y, float z, float (&Y)[RTGS_SH_COEFFS]) {
   constexpr float c0 = 0.97720502380583984f, c1 = 2.1850968611841584f, c2 = 1.2615662610100802f,
@@ -270,7 +300,7 @@ __device__ __forceinline__ void sh_basis(float x, float y, float z, float (&Y)[R
 }
 
 template <bool kHasSh>
-__global__ __launch_bounds__(kTraceBlock, 4) void k_trace(const TraceArgs a,
+__global__ __launch_bounds__(kTraceBlock, RTGS_WAVES_PER_SIMD) void k_trace(const TraceArgs a,
                                                           const float4* __restrict__ bbox,
                                                           const float4* __restrict__ slab_bbox,
                                                           const float4* __restrict__ rec,
@@ -280,7 +310,7 @@ __global__ __launch_bounds__(kTraceBlock, 4) void k_trace(const TraceArgs a,
   __shared__ float4 s_bb[kListCap];
   __shared__ int s_idx[kListCap];
   __shared__ int s_wcnt[2][kWavesPerTile];
-  __shared__ int s_n;
+  __shared__ int s_cnt[kBatch];
 
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
@@ -317,18 +347,26 @@ __global__ __launch_bounds__(kTraceBlock, 4) void k_trace(const TraceArgs a,
   float start = 0.f;
   if ((a.flags & RTGS_TRACE_RESUME) && in_img) start = a.start[pix * a.start_stride];
 
+#if RTGS_INSERT == 0
   unsigned long long key[RTGS_MAX_DEPTH];
-  float wexp[RTGS_MAX_DEPTH];
   constexpr unsigned long long kEmpty = 0x7F800000FFFFFFFFull;  // (+inf, -1)
+#else
+  unsigned key[RTGS_MAX_DEPTH], kidx[RTGS_MAX_DEPTH];
+  constexpr unsigned kEmpty = 0x7F800000u;  // +inf
+#endif
+  float wexp[RTGS_MAX_DEPTH];
 #pragma unroll
-  for (int k = 0; k < RTGS_MAX_DEPTH; ++k) { key[k] = kEmpty; wexp[k] = 0.f; }
+  for (int k = 0; k < RTGS_MAX_DEPTH; ++k) {
+    key[k] = kEmpty; wexp[k] = 0.f;
+#if RTGS_INSERT != 0
+    kidx[k] = 0u;
+#endif
+  }
   int nvalid = 0;   // entries in this lane's list
   int fill = 0;     // wave-uniform max of nvalid
 
   const unsigned long long lane_lt = (1ull << lane) - 1ull;
   const int nslabs = (a.n + kSlab - 1) / kSlab;
-  if (tid == 0) s_n = 0;
-
   int scnt = 0;  // surviving slabs listed so far: identical in every thread
   for (int sbase = 0, par = 0; sbase < nslabs; sbase += kSlabStep, par ^= 1) {
     // ---- scan slab bounds; keep the slabs that touch the macro-tile.  The list is built
@@ -370,27 +408,47 @@ __global__ __launch_bounds__(kTraceBlock, 4) void k_trace(const TraceArgs a,
 
     for (int b0 = 0; b0 < scnt; b0 += kBatch) {
       // ---- expand a batch of surviving slabs: one wave per slab, one lane per Gaussian.
-      // Slot order in the list depends on wave timing, the image does not (see list_insert).
+      // Two passes (count, barrier, prefix, write) instead of an atomic cursor, so that the
+      // survivor list is in stream order on every run: equal t1 keys then resolve identically.
       const int bend = min(scnt, b0 + kBatch);
-      for (int k = b0 + wave; k < bend; k += kWavesPerTile) {
-        const int g = s_slab[k] * kSlab + lane;
-        float4 gb = make_float4(kInf, kInf, -kInf, -kInf);
-        if (g < a.n) gb = bbox[g];
-        const bool keep = gb.x <= mXhi && gb.z >= mXlo && gb.y <= mYhi && gb.w >= mYlo;
-        const unsigned long long m = __ballot(keep);
-        if (m) {
-          int wb = 0;
-          if (lane == 0) wb = atomicAdd(&s_n, __popcll(m));
-          wb = __builtin_amdgcn_readfirstlane(wb);
-          if (keep) {
-            const int slot = wb + __popcll(m & lane_lt);
-            s_idx[slot] = g;
-            s_bb[slot] = gb;
-          }
+      float4 gb[kSlabsPerWave];
+      unsigned long long gm[kSlabsPerWave];
+#pragma unroll
+      for (int q = 0; q < kSlabsPerWave; ++q) {
+        const int k = b0 + q * kWavesPerTile + wave;
+        gb[q] = make_float4(kInf, kInf, -kInf, -kInf);
+        if (k < bend) {
+          const int g = s_slab[k] * kSlab + lane;
+          if (g < a.n) gb[q] = bbox[g];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < kSlabsPerWave; ++q) {
+        const bool keep = gb[q].x <= mXhi && gb[q].z >= mXlo && gb[q].y <= mYhi && gb[q].w >= mYlo;
+        gm[q] = __ballot(keep);
+        if (lane == 0) s_cnt[q * kWavesPerTile + wave] = __popcll(gm[q]);
+      }
+      __syncthreads();
+      int cnt = 0;
+      int goff[kSlabsPerWave];
+#pragma unroll
+      for (int q = 0; q < kSlabsPerWave; ++q) {
+#pragma unroll
+        for (int w = 0; w < kWavesPerTile; ++w) {
+          if (w == wave) goff[q] = cnt;
+          cnt += s_cnt[q * kWavesPerTile + w];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < kSlabsPerWave; ++q) {
+        if ((gm[q] >> lane) & 1ull) {
+          const int k = b0 + q * kWavesPerTile + wave;
+          const int slot = goff[q] + __popcll(gm[q] & lane_lt);
+          s_idx[slot] = s_slab[k] * kSlab + lane;
+          s_bb[slot] = gb[q];
         }
       }
       __syncthreads();
-      const int cnt = s_n;
 
       // ---- every wave: survivors vs its own 8x8 tile, then exact per-ray tests ----
       if (wave_live) {
@@ -455,14 +513,23 @@ __global__ __launch_bounds__(kTraceBlock, 4) void k_trace(const TraceArgs a,
             const float t1 = (q4.y / (sqrtf(e) - bq)) * dlen;
 #endif
             const bool cand = hit && t1 > start && t1 < kInf;  // scene.py:433
+#if RTGS_INSERT == 0
             const unsigned long long kn =
                 cand ? (((unsigned long long)__float_as_uint(t1) << 32) | (unsigned)gi) : ~0ull;
+#else
+            const unsigned kn = cand ? __float_as_uint(t1) : ~0u;
+#endif
             const bool ins = kn < key[RTGS_MAX_DEPTH - 1];
             if (__any(ins)) {
 #if RTGS_FAST_DIV
-              list_insert(key, wexp, kn, e * __builtin_amdgcn_rcpf(A), fill);
+              const float wn = e * __builtin_amdgcn_rcpf(A);
 #else
-              list_insert(key, wexp, kn, e / A, fill);
+              const float wn = e / A;
+#endif
+#if RTGS_INSERT == 0
+              list_insert(key, wexp, kn, wn, fill);
+#else
+              list_insert_swap(key, kidx, wexp, kn, (unsigned)gi, wn);
 #endif
               if (__any(ins && nvalid == fill)) fill = min(fill + 1, RTGS_MAX_DEPTH - 1);
               nvalid += (ins && nvalid < RTGS_MAX_DEPTH) ? 1 : 0;
@@ -471,8 +538,6 @@ __global__ __launch_bounds__(kTraceBlock, 4) void k_trace(const TraceArgs a,
         }
       }
       __syncthreads();  // everyone is done with the list before the next batch refills it
-      if (tid == 0) s_n = 0;
-      __syncthreads();
     }
     scnt = 0;
   }
@@ -494,37 +559,62 @@ __global__ __launch_bounds__(kTraceBlock, 4) void k_trace(const TraceArgs a,
   int nhit = 0;
   float last_t = 0.f;
   unsigned prev_tbits = 0u;
+  constexpr int kGroup = 8;   // colour/opacity gathers issued together: 2 latencies, not 16
+  bool done = false;
 #pragma unroll
-  for (int k = 0; k < RTGS_MAX_DEPTH; ++k) {
-    if (k < a.depth) {
-      const unsigned tbits = (unsigned)(key[k] >> 32);
-      // an exact repeat of the previous entry distance is what the reference's strict
-      // `t1 > ray.start` drops (scene.py:433 after ray_tracer.py:101)
-      const bool valid = tbits < 0x7F800000u && tbits != prev_tbits;
-      const bool live = valid && !(a.t_cutoff > 0.f && T < a.t_cutoff);
-      if (a.t_cutoff > 0.f && !__any(live)) break;
-      prev_tbits = tbits;
+  for (int k0 = 0; k0 < RTGS_MAX_DEPTH; k0 += kGroup) {
+    if (k0 >= a.depth || done) break;
+    float4 cog[kGroup];
+#pragma unroll
+    for (int j = 0; j < kGroup; ++j) {
+      const int k = k0 + j;
+#if RTGS_INSERT == 0
+      const unsigned tb = (unsigned)(key[k] >> 32);
       const unsigned gi = (unsigned)(key[k] & 0xFFFFFFFFull);
-      float4 co = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (valid) co = colop[gi];
-      if (kHasSh) {
-        if (valid) {
-          const float* s = sh + (size_t)gi * (RTGS_SH_COEFFS * 3);
+#else
+      const unsigned tb = key[k];
+      const unsigned gi = kidx[k];
+#endif
+      cog[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (tb < 0x7F800000u) cog[j] = colop[gi];
+    }
 #pragma unroll
-          for (int q = 0; q < RTGS_SH_COEFFS; ++q) {
-            co.x += Ysh[q] * s[3 * q + 0];
-            co.y += Ysh[q] * s[3 * q + 1];
-            co.z += Ysh[q] * s[3 * q + 2];
+    for (int j = 0; j < kGroup; ++j) {
+      const int k = k0 + j;
+      if (k < a.depth && !done) {
+#if RTGS_INSERT == 0
+        const unsigned tbits = (unsigned)(key[k] >> 32);
+        const unsigned gi = (unsigned)(key[k] & 0xFFFFFFFFull);
+#else
+        const unsigned tbits = key[k];
+        const unsigned gi = kidx[k];
+#endif
+        // an exact repeat of the previous entry distance is what the reference's strict
+        // `t1 > ray.start` drops (scene.py:433 after ray_tracer.py:101)
+        const bool valid = tbits < 0x7F800000u && tbits != prev_tbits;
+        const bool live = valid && !(a.t_cutoff > 0.f && T < a.t_cutoff);
+        if (a.t_cutoff > 0.f && !__any(live)) { done = true; continue; }
+        prev_tbits = tbits;
+        float4 co = cog[j];
+        if (kHasSh) {
+          if (valid) {
+            const float* sp = sh + (size_t)gi * (RTGS_SH_COEFFS * 3);
+#pragma unroll
+            for (int q = 0; q < RTGS_SH_COEFFS; ++q) {
+              co.x += Ysh[q] * sp[3 * q + 0];
+              co.y += Ysh[q] * sp[3 * q + 1];
+              co.z += Ysh[q] * sp[3 * q + 2];
+            }
           }
         }
-      }
-      const float alpha = co.w * expf(wexp[k] - 3.0f);  // == exp(-d^T S^-1 d) at the chord midpoint
-      if (valid) {
-        const float wa = T * alpha;
-        L0 += wa * co.x; L1 += wa * co.y; L2 += wa * co.z;
-        T *= 1.0f - alpha;
-        last_t = __uint_as_float(tbits);
-        ++nhit;
+        const float alpha = co.w * expf(wexp[k] - 3.0f);  // == exp(-d^T S^-1 d) at the chord midpoint
+        if (valid) {
+          const float wa = T * alpha;
+          L0 += wa * co.x; L1 += wa * co.y; L2 += wa * co.z;
+          T *= 1.0f - alpha;
+          last_t = __uint_as_float(tbits);
+          ++nhit;
+        }
       }
     }
   }
