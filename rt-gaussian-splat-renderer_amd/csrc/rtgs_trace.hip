@@ -50,6 +50,9 @@ namespace {
 #ifndef RTGS_INSERT
 #define RTGS_INSERT 1     // 0: compare/select bubble on 64-bit (t1,index) keys (7 VALU/level);
 #endif                    // 1: v_cmpx + v_swap_b32 under EXEC on 32-bit t1 keys (4 VALU/level)
+#ifndef RTGS_ABLATE
+#define RTGS_ABLATE 0     // timing-only builds (wrong images): 1 no insertion, 2 no hit path,
+#endif                    // 3 no per-candidate loop, 4 no slab expansion either
 #ifndef RTGS_WAVES_PER_SIMD
 #define RTGS_WAVES_PER_SIMD 4   // __launch_bounds__ second argument: caps VGPRs at 512/this
 #endif
@@ -58,12 +61,12 @@ namespace {
 #endif
 
 constexpr int kSlab = 64;                                 // Gaussians per slab = one wave
-constexpr int kSlabIters = 4;                             // slab bounds in flight per thread
+constexpr int kSlabIters = kTraceBlock >= 1024 ? 1 : 4;    // slab bounds in flight per thread
 constexpr int kSlabStep = kSlabIters * kTraceBlock;       // slabs scanned per barrier
 constexpr int kSlabCap = 2048;                            // LDS list of surviving slabs
-constexpr int kListCap = 1024;                            // LDS list of surviving Gaussians
-constexpr int kBatch = kListCap / kSlab;                  // slabs expanded per batch
-constexpr int kSlabsPerWave = kBatch / kWavesPerTile;     // slabs one wave expands per batch
+constexpr int kSlabsPerWave = 4;                          // slabs one wave expands per batch
+constexpr int kBatch = kSlabsPerWave * kWavesPerTile;     // slabs expanded per batch
+constexpr int kListCap = kBatch * kSlab;                  // LDS list of surviving Gaussians
 static_assert(kBatch % kWavesPerTile == 0, "batch must split evenly over the waves");
 static_assert(kSlabCap >= 2 * kSlabStep || kSlabCap >= kSlabStep + 64, "slab list too small");
 
@@ -259,22 +262,38 @@ __device__ __forceinline__ void list_insert(unsigned long long (&key)[RTGS_MAX_D
 // carried key is smaller, three v_swap_b32 exchange (t1, index, exponent) in those lanes only,
 // and EXEC is restored.  4 VALU + 1 SALU per level.  Keys are the t1 bits alone; equal t1 keep
 // their arrival order, which k_trace makes deterministic (stream order).
+#define RTGS_SWAP_LEVEL(k)                                                                 \
+  asm volatile(                                                                            \
+      "v_cmpx_lt_u32_e32 vcc, %0, %3\n\t"                                                   \
+      "s_cbranch_execz .Lskip%=\n\t"                                                        \
+      "v_swap_b32 %0, %3\n\t"                                                               \
+      "v_swap_b32 %1, %4\n\t"                                                               \
+      "v_swap_b32 %2, %5\n"                                                                 \
+      ".Lskip%=:\n\t"                                                                       \
+      "s_mov_b64 exec, %6"                                                                 \
+      : "+v"(tn), "+v"(in), "+v"(wn), "+v"(kt[k]), "+v"(ki[k]), "+v"(kw[k])                \
+      : "s"(ex)                                                                            \
+      : "vcc")
+
 __device__ __forceinline__ void list_insert_swap(unsigned (&kt)[RTGS_MAX_DEPTH], unsigned (&ki)[RTGS_MAX_DEPTH],
                                                  float (&kw)[RTGS_MAX_DEPTH], unsigned tn, unsigned in,
-                                                 float wn) {
+                                                 float wn, int fill) {
+  // `fill` (wave-uniform) = the longest list in the wave: slots above it are empty in every
+  // lane, and the carried element has been placed by then, so the bubble stops there.
   const unsigned long long ex = __builtin_amdgcn_read_exec();
-#pragma unroll
-  for (int k = 0; k < RTGS_MAX_DEPTH; ++k) {
-    asm volatile(
-        "v_cmpx_lt_u32_e32 vcc, %0, %3\n\t"
-        "v_swap_b32 %0, %3\n\t"
-        "v_swap_b32 %1, %4\n\t"
-        "v_swap_b32 %2, %5\n\t"
-        "s_mov_b64 exec, %6"
-        : "+v"(tn), "+v"(in), "+v"(wn), "+v"(kt[k]), "+v"(ki[k]), "+v"(kw[k])
-        : "s"(ex)
-        : "vcc");
-  }
+  RTGS_SWAP_LEVEL(0); RTGS_SWAP_LEVEL(1); RTGS_SWAP_LEVEL(2); RTGS_SWAP_LEVEL(3);
+#if RTGS_FILL_SKIP
+  if (fill < 4) return;
+#endif
+  RTGS_SWAP_LEVEL(4); RTGS_SWAP_LEVEL(5); RTGS_SWAP_LEVEL(6); RTGS_SWAP_LEVEL(7);
+#if RTGS_FILL_SKIP
+  if (fill < 8) return;
+#endif
+  RTGS_SWAP_LEVEL(8); RTGS_SWAP_LEVEL(9); RTGS_SWAP_LEVEL(10); RTGS_SWAP_LEVEL(11);
+#if RTGS_FILL_SKIP
+  if (fill < 12) return;
+#endif
+  RTGS_SWAP_LEVEL(12); RTGS_SWAP_LEVEL(13); RTGS_SWAP_LEVEL(14); RTGS_SWAP_LEVEL(15);
 }
 
 // gaussian.py:149-163, including the y_33 quirk (5 z^2 - 3 z).
@@ -406,6 +425,9 @@ __global__ __launch_bounds__(kTraceBlock, RTGS_WAVES_PER_SIMD) void k_trace(cons
     if (scnt + kSlabStep <= kSlabCap && !last) continue;
     __syncthreads();  // the slab list is complete
 
+#if RTGS_ABLATE == 4
+    scnt = 0;
+#endif
     for (int b0 = 0; b0 < scnt; b0 += kBatch) {
       // ---- expand a batch of surviving slabs: one wave per slab, one lane per Gaussian.
       // Two passes (count, barrier, prefix, write) instead of an atomic cursor, so that the
@@ -459,6 +481,10 @@ __global__ __launch_bounds__(kTraceBlock, RTGS_WAVES_PER_SIMD) void k_trace(cons
           if (slot < cnt) { g = s_idx[slot]; wb = s_bb[slot]; }
           const bool pass = wb.x <= wXhi && wb.z >= wXlo && wb.y <= wYhi && wb.w >= wYlo;
           unsigned long long m = __ballot(pass);
+#if RTGS_ABLATE >= 3
+          asm volatile("" ::"s"(m));
+          m = 0;
+#endif
 #if RTGS_REC_MODE == 0
           float4 r0, r1, r2, r3, r4;
           r0 = r1 = r2 = r3 = r4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -500,6 +526,10 @@ __global__ __launch_bounds__(kTraceBlock, RTGS_WAVES_PER_SIMD) void k_trace(cons
             const float y = Y - q0.y;
             const float e = q0.z - ((q1.y * x + q1.z * y - q0.w) * x + (q1.w * y - q1.x) * y);
             bool hit = e > 0.f && in_img;
+#if RTGS_ABLATE == 2
+            asm volatile("" ::"v"(e));
+            continue;
+#endif
             if (!__any(hit)) continue;
             const float A = q2.x + q2.y * x + q2.z * y + (q2.w * x + q3.x * y) * x + (q3.y * y) * y;
             const float bq = q3.z + q3.w * x + q4.x * y;
@@ -526,10 +556,12 @@ __global__ __launch_bounds__(kTraceBlock, RTGS_WAVES_PER_SIMD) void k_trace(cons
 #else
               const float wn = e / A;
 #endif
-#if RTGS_INSERT == 0
+#if RTGS_ABLATE == 1
+              asm volatile("" ::"v"(kn), "v"(wn));
+#elif RTGS_INSERT == 0
               list_insert(key, wexp, kn, wn, fill);
 #else
-              list_insert_swap(key, kidx, wexp, kn, (unsigned)gi, wn);
+              list_insert_swap(key, kidx, wexp, kn, (unsigned)gi, wn, fill);
 #endif
               if (__any(ins && nvalid == fill)) fill = min(fill + 1, RTGS_MAX_DEPTH - 1);
               nvalid += (ins && nvalid < RTGS_MAX_DEPTH) ? 1 : 0;
