@@ -40,7 +40,11 @@ namespace {
 
 // Tuning switches; defaults = the fastest measured on MI355X (c3, tools/variants.sh, round 1):
 //   REC_MODE 0 / 1 / 2 = 0.426 / 0.377 / 0.406 ms, FILL_SKIP 1 = 2x slower (branch chain),
-//   FAST_DIV 0 = +8 %, INSERT 0 / 1 = 0.374 / 0.336 ms, WAVES_PER_SIMD 5 spills (0.362 ms).
+//   FAST_DIV 0 = +8 %, INSERT 0 / 1 = 0.374 / 0.336 ms (0.321 with the execz level skip);
+//   SLAB_ITERS/SLABS_PER_WAVE/COLOR_GROUP 4/4/8 -> 2/2/4: 114 -> 96 VGPRs, 0.321 -> 0.305 ms;
+//   5 or 6 waves/SIMD measure the same as 4 (VALU-bound, not latency-bound); 32x32 tiles 0.475,
+//   8x8 single-wave workgroups 0.473; LDS append lists with sorted arrival (k_trace2, removed):
+//   1.21 ms (0.45 without its slow path, 2 waves/SIMD).
 #ifndef RTGS_REC_MODE
 #define RTGS_REC_MODE 1   // 0: record held by a lane, broadcast with v_readlane; 1: scalar loads;
 #endif                    // 2: scalar loads prefetched one candidate ahead
@@ -61,10 +65,19 @@ namespace {
 #endif
 
 constexpr int kSlab = 64;                                 // Gaussians per slab = one wave
-constexpr int kSlabIters = kTraceBlock >= 1024 ? 1 : 4;    // slab bounds in flight per thread
+#ifndef RTGS_SLAB_ITERS
+#define RTGS_SLAB_ITERS 2
+#endif
+#ifndef RTGS_SLABS_PER_WAVE
+#define RTGS_SLABS_PER_WAVE 2
+#endif
+#ifndef RTGS_COLOR_GROUP
+#define RTGS_COLOR_GROUP 4
+#endif
+constexpr int kSlabIters = kTraceBlock >= 1024 ? 1 : RTGS_SLAB_ITERS;  // slab bounds in flight per thread
 constexpr int kSlabStep = kSlabIters * kTraceBlock;       // slabs scanned per barrier
 constexpr int kSlabCap = 2048;                            // LDS list of surviving slabs
-constexpr int kSlabsPerWave = 4;                          // slabs one wave expands per batch
+constexpr int kSlabsPerWave = RTGS_SLABS_PER_WAVE;        // slabs one wave expands per batch
 constexpr int kBatch = kSlabsPerWave * kWavesPerTile;     // slabs expanded per batch
 constexpr int kListCap = kBatch * kSlab;                  // LDS list of surviving Gaussians
 static_assert(kBatch % kWavesPerTile == 0, "batch must split evenly over the waves");
@@ -591,7 +604,7 @@ __global__ __launch_bounds__(kTraceBlock, RTGS_WAVES_PER_SIMD) void k_trace(cons
   int nhit = 0;
   float last_t = 0.f;
   unsigned prev_tbits = 0u;
-  constexpr int kGroup = 8;   // colour/opacity gathers issued together: 2 latencies, not 16
+  constexpr int kGroup = RTGS_COLOR_GROUP;   // colour/opacity gathers issued together
   bool done = false;
 #pragma unroll
   for (int k0 = 0; k0 < RTGS_MAX_DEPTH; k0 += kGroup) {
