@@ -68,8 +68,9 @@ class TileParallelRenderer:
     """Renders whole frames on `world` ranks; the image lands in ``framebuffer`` on rank `dst`."""
 
     def __init__(self, scene=None, camera=None, depth: int = 16, rank: int = 0, world: int = 1,
-                 t_cutoff: float = 0.0, dst: int = 0, group=None, backend=None):
+                 t_cutoff: float = 0.0, dst: int = 0, group=None, backend=None, gather_fn=None):
         self.backend = backend if backend is not None else HipBackend(scene, camera, depth, t_cutoff)
+        self._gather = gather_fn if gather_fn is not None else dist.gather   # injectable for tests
         self.rank, self.world, self.dst, self.group = int(rank), int(world), int(dst), group
         b = self.backend
         self.TILE = int(b.tile)
@@ -98,8 +99,8 @@ class TileParallelRenderer:
         if self.local_tiles:
             b.trace(self.compact[k], self.rank, self.world, compact=True)
         glist = list(self.gathered[k].unbind(0)) if self.rank == self.dst else None
-        work = dist.gather(self.compact[k], gather_list=glist, dst=self.dst, group=self.group,
-                           async_op=True)
+        work = self._gather(self.compact[k], gather_list=glist, dst=self.dst, group=self.group,
+                            async_op=True)
         prev, self._pending = self._pending, (work, k)
         self._complete(prev)
 

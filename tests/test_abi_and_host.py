@@ -135,3 +135,31 @@ def test_records_have_the_reference_defaults():
     assert z.rotation == vec4(0) and z.scale == vec3(0) and z.opacity == 0
     with pytest.raises(NotImplementedError):
         g.bounding_box()
+
+
+def test_cli_orbit_pose_and_image_writer(tmp_path):
+    # reference __main__.py:120-142: theta=0, phi=pi/2, r=1 puts the camera at (1,0,0) looking at
+    # the origin with world Z up; camera axes: +x right, +y up, -z forward (coordinate-system.md)
+    import zlib
+    from rtgs.__main__ import orbit_pose, write_image
+    pos, q = orbit_pose(0.0, np.pi / 2, 1.0)
+    assert pos == pytest.approx([1, 0, 0], abs=1e-12) and np.linalg.norm(q) == pytest.approx(1)
+    fwd = ref.quat_rot_vec3(q, (0, 0, -1))
+    up = ref.quat_rot_vec3(q, (0, 1, 0))
+    right = ref.quat_rot_vec3(q, (1, 0, 0))
+    assert fwd == pytest.approx([-1, 0, 0], abs=1e-12) and up == pytest.approx([0, 0, 1], abs=1e-12)
+    assert right == pytest.approx([0, 1, 0], abs=1e-12)
+    for th, ph in [(0.7, 1.1), (2.5, 0.4), (-1.0, 2.6)]:
+        p, q = orbit_pose(th, ph, 2.0, (0.1, 0.2, 0.3))
+        f = ref.quat_rot_vec3(q, (0, 0, -1))
+        assert f == pytest.approx(-(p - np.array([0.1, 0.2, 0.3])) / 2.0, abs=1e-9)
+    disp = np.zeros((3, 2, 3), np.float32)       # (W, H, 3), (0,0) bottom-left
+    disp[0, 0] = (1, 0, 0)
+    write_image(str(tmp_path / "a.ppm"), disp)
+    data = (tmp_path / "a.ppm").read_bytes()
+    assert data.startswith(b"P6\n3 2\n255\n")
+    px = np.frombuffer(data[len(b"P6\n3 2\n255\n"):], np.uint8).reshape(2, 3, 3)
+    assert px[1, 0].tolist() == [255, 0, 0] and px[0].sum() == 0    # bottom-left pixel is in the LAST row
+    write_image(str(tmp_path / "a.png"), disp)
+    png = (tmp_path / "a.png").read_bytes()
+    assert png.startswith(b"\x89PNG\r\n\x1a\n") and b"IEND" in png

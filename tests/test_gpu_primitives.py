@@ -226,3 +226,15 @@ def test_disp_and_fill():
     assert float((tr.disp_buf - 4.0).abs().max()) == 0.0
     tr.clear_attenuation()
     assert float(tr.attenuation_buf.min()) == 1.0 == float(tr.attenuation_buf.max())
+
+
+def test_cli_renders_headless(tmp_path):
+    # reference CLI flags (__main__.py:34-85) on the bundled fixture and on a synthetic scene
+    from rtgs.__main__ import main
+    out = tmp_path / "ply.ppm"
+    assert main(["-o", os.path.join(U.GOLDEN, "test.ply"), "-r", "96,64", "-f", "60", "-d", "4", "-s", "2",
+                 "--scale", "8", "--radius", "3", "--out", str(out)]) == 0
+    assert out.stat().st_size == len(b"P6\n96 64\n255\n") + 96 * 64 * 3
+    out2 = tmp_path / "syn.png"
+    assert main(["--synthetic", "2000", "-r", "128,72", "--radius", "3", "--one-pass", "--out", str(out2)]) == 0
+    assert out2.read_bytes().startswith(b"\x89PNG")

@@ -285,3 +285,48 @@ def test_error_codes_become_exceptions():
         rtgs.Scene().native()
     with pytest.raises(ValueError):
         rtgs.RayTracer((8, 8), scene, camera)
+
+
+class _FakeWork:
+    def wait(self):
+        return True
+
+
+class _FakeComm:
+    """Stands in for torch.distributed.gather when all `world` ranks are emulated sequentially in
+    one process (non-destination ranks first): everything but RCCL itself runs for real."""
+
+    def __init__(self):
+        self.rank = 0
+        self.sent = {}
+
+    def gather(self, tensor, gather_list=None, dst=0, group=None, async_op=False):
+        if self.rank != dst:
+            self.sent[self.rank] = tensor.clone()
+        else:
+            for r, out in enumerate(gather_list):
+                out.copy_(tensor if r == dst else self.sent.pop(r))
+        return _FakeWork()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_tile_parallel_frame_loop_end_to_end(world):
+    from rtgs.parallel import TileParallelRenderer
+    arrays, cam, depth = U.case("oblique")
+    scene, camera, tracer = U.build(arrays, cam)
+    tracer.trace(depth)
+    whole = tracer.sample_buf.clone()
+    comm = _FakeComm()
+    ranks = [TileParallelRenderer(scene, camera, depth=depth, rank=r, world=world, gather_fn=comm.gather)
+             for r in range(world)]
+    assert sum(r.local_tiles for r in ranks) == ranks[0].total_tiles
+    for frame in range(3):                       # exercises both halves of the double buffer
+        for r in list(range(1, world)) + [0]:
+            comm.rank = r
+            ranks[r].render_frame()
+    for r in list(range(1, world)) + [0]:
+        comm.rank = r
+        ranks[r].finish()
+    torch.cuda.synchronize()
+    assert torch.equal(ranks[0].framebuffer, whole)
+    assert all(r.framebuffer is None for r in ranks[1:])
