@@ -54,6 +54,9 @@ namespace {
 #ifndef RTGS_INSERT
 #define RTGS_INSERT 1     // 0: compare/select bubble on 64-bit (t1,index) keys (7 VALU/level);
 #endif                    // 1: v_cmpx + v_swap_b32 under EXEC on 32-bit t1 keys (4 VALU/level)
+#ifndef RTGS_STAMPS
+#define RTGS_STAMPS 0     // diagnostic build: per-phase s_memtime stamps of wave 0 into the buffer
+#endif                    // passed as attenuation_buf (8 x u64 per block); never quote its run time
 #ifndef RTGS_ABLATE
 #define RTGS_ABLATE 0     // timing-only builds (wrong images): 1 no insertion, 2 no hit path,
 #endif                    // 3 no per-candidate loop, 4 no slab expansion either
@@ -399,6 +402,10 @@ __global__ __launch_bounds__(kTraceBlock, RTGS_WAVES_PER_SIMD) void k_trace(cons
 
   const unsigned long long lane_lt = (1ull << lane) - 1ull;
   const int nslabs = (a.n + kSlab - 1) / kSlab;
+#if RTGS_STAMPS
+  unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
+  st[0] = __builtin_amdgcn_s_memtime();
+#endif
   int scnt = 0;  // surviving slabs listed so far: identical in every thread
   for (int sbase = 0, par = 0; sbase < nslabs; sbase += kSlabStep, par ^= 1) {
     // ---- scan slab bounds; keep the slabs that touch the macro-tile.  The list is built
@@ -437,6 +444,9 @@ __global__ __launch_bounds__(kTraceBlock, RTGS_WAVES_PER_SIMD) void k_trace(cons
     const bool last = sbase + kSlabStep >= nslabs;
     if (scnt + kSlabStep <= kSlabCap && !last) continue;
     __syncthreads();  // the slab list is complete
+#if RTGS_STAMPS
+    if (st[1] == 0) st[1] = __builtin_amdgcn_s_memtime();
+#endif
 
 #if RTGS_ABLATE == 4
     scnt = 0;
@@ -485,6 +495,9 @@ __global__ __launch_bounds__(kTraceBlock, RTGS_WAVES_PER_SIMD) void k_trace(cons
       }
       __syncthreads();
 
+#if RTGS_STAMPS
+      if (st[2] == 0) st[2] = __builtin_amdgcn_s_memtime();
+#endif
       // ---- every wave: survivors vs its own 8x8 tile, then exact per-ray tests ----
       if (wave_live) {
         for (int c = 0; c < cnt; c += kWave) {
@@ -587,9 +600,14 @@ __global__ __launch_bounds__(kTraceBlock, RTGS_WAVES_PER_SIMD) void k_trace(cons
     scnt = 0;
   }
 
+#if RTGS_STAMPS
+  st[3] = __builtin_amdgcn_s_memtime();
+#endif
   // ---- front-to-back compositing of the sorted list (ray_tracer.py:88-104) ----
   float T = 1.f;
+#if !RTGS_STAMPS
   if ((a.flags & RTGS_TRACE_RESUME) && in_img) T = a.att[pix];
+#endif
   float L0 = 0.f, L1 = 0.f, L2 = 0.f;
   float Ysh[RTGS_SH_COEFFS];
   if (kHasSh) {
@@ -675,8 +693,17 @@ __global__ __launch_bounds__(kTraceBlock, RTGS_WAVES_PER_SIMD) void k_trace(cons
     }
     *reinterpret_cast<Rgb*>(o) = Rgb{L0, L1, L2};
   }
+#if RTGS_STAMPS
+  st[4] = __builtin_amdgcn_s_memtime();
+  if (tid == 0 && a.att) {
+    unsigned long long* sp = reinterpret_cast<unsigned long long*>(a.att) + (size_t)blockIdx.x * 8;
+    for (int k = 0; k < 5; ++k) sp[k] = st[k];
+  }
+#endif
   if (in_img) {
+#if !RTGS_STAMPS
     if (a.att) a.att[pix] = T;
+#endif
     // ray_tracer.py:99-104: start = t1 + EPS after a hit, +inf after a miss
     if (a.start) a.start[pix * a.start_stride] = (nhit == a.depth) ? last_t + 1e-8f : kInf;
   }

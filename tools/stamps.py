@@ -1,0 +1,44 @@
+"""Diagnostic: per-phase s_memtime profile of k_trace (needs a -DRTGS_STAMPS=1 build in RTGS_HIP_LIB)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "rt-gaussian-splat-renderer_amd"), ROOT]
+import numpy as np, torch
+import rtgs
+from rtgs import synthetic, _native as nat
+from rtgs.parallel import HipBackend
+cfg = synthetic.CONFIGS["c3"]
+arrays = synthetic.make_config_scene(cfg); cam = synthetic.bench_camera(cfg.width, cfg.height)
+scene = rtgs.Scene.from_arrays(**arrays)
+camera = rtgs.Camera(cam["position"], cam["rotation"], (cfg.width, cfg.height), (cam["fx"], cam["fy"]))
+b = HipBackend(scene, camera, 16); T = b.tile
+total = ((cfg.width + T - 1) // T) * ((cfg.height + T - 1) // T)
+b.project()
+for world in (1, 8):
+    per = (total + world - 1) // world
+    compact = b.alloc(per, T, T, 3)
+    stamps = torch.zeros((per, 8), dtype=torch.int64, device="cuda")
+    params = nat.RtgsTraceParams(16, 0.0, 0, world, nat.TRACE_COMPACT)
+    for _ in range(3):
+        nat.check(nat.lib().rtgs_trace(scene.native(), camera.native(), params, nat.ptr(compact), stamps.data_ptr(),
+                                       None, 1, nat.ptr(b.workspace), b.workspace.numel(), 1, nat.stream()))
+    torch.cuda.synchronize()
+    s = stamps.cpu().numpy()[:, :5].astype(np.float64)
+    s = s[s[:, 0] > 0]
+    d = np.diff(s, axis=1)                      # scan, expand, process, composite
+    t0 = s[:, 0].min()
+    print(f"world {world}: {len(s)} blocks; kernel span {(s[:,4].max()-t0)/100:.1f} us (100 MHz ticks?)")
+    names = ["scan", "expand", "process", "composite"]
+    for k, nme in enumerate(names):
+        print(f"   {nme:10s} mean {d[:,k].mean():9.0f}  p50 {np.median(d[:,k]):9.0f}  p95 {np.percentile(d[:,k],95):9.0f} ticks")
+    life = s[:, 4] - s[:, 0]
+    print(f"   lifetime   mean {life.mean():9.0f}  p50 {np.median(life):9.0f}  max {life.max():9.0f}; start spread {(s[:,0].max()-t0):.0f}")
+    if world == 1:
+        tx = (cfg.width + T - 1) // T
+        order = np.argsort(-life)
+        print("   slowest tiles (tx,ty,cycles):", [(int(i % tx), int(i // tx), int(life[i])) for i in order[:10]])
+        grid = np.zeros(((cfg.height + T - 1) // T, tx)); grid.flat[:len(life)] = life
+        # coarse 8x10 heat map of mean lifetime (kcycles)
+        H, W = grid.shape
+        for r in range(7, -1, -1):
+            row = grid[r * H // 8:(r + 1) * H // 8]
+            print("   " + " ".join(f"{row[:, c * W // 10:(c + 1) * W // 10].mean() / 1000:5.0f}" for c in range(10)))
