@@ -84,6 +84,11 @@ typedef struct RtgsTraceParams {
   int32_t tile_first;   /* this shard renders macro-tiles tile_first, +tile_step, ...     */
   int32_t tile_step;    /* (rank, world_size); (0, 1) = whole frame                       */
   uint32_t flags;
+  const int32_t* tile_order; /* optional DEVICE array, a permutation of 0..local_tiles-1: workgroup b
+                           renders the shard's local tile tile_order[b] (NULL = b).  Scheduling
+                           only: the image and the compact layout do not depend on it.  Work-
+                           groups b and b + 256 share a CU on MI355X, so an order that sorts the
+                           tiles by expected cost gives every CU a mix of heavy and light tiles. */
 } RtgsTraceParams;
 
 int rtgs_abi_version(void);

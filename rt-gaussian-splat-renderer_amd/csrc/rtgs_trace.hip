@@ -38,22 +38,19 @@
 namespace rtgs {
 namespace {
 
-// Tuning switches; defaults = the fastest measured on MI355X (c3, tools/variants.sh, round 1):
-//   REC_MODE 0 / 1 / 2 = 0.426 / 0.377 / 0.406 ms, FILL_SKIP 1 = 2x slower (branch chain),
-//   FAST_DIV 0 = +8 %, INSERT 0 / 1 = 0.374 / 0.336 ms (0.321 with the execz level skip);
-//   SLAB_ITERS/SLABS_PER_WAVE/COLOR_GROUP 4/4/8 -> 2/2/4: 114 -> 96 VGPRs, 0.321 -> 0.305 ms;
-//   5 or 6 waves/SIMD measure the same as 4 (VALU-bound, not latency-bound); 32x32 tiles 0.475,
-//   8x8 single-wave workgroups 0.473; LDS append lists with sorted arrival (k_trace2, removed):
-//   1.21 ms (0.45 without its slow path, 2 waves/SIMD).
+// Tuning switches; defaults = the fastest measured on MI355X (c3, tools/variants.sh, round 1).
+// Other things tried and dropped, same scene: record broadcast with v_readlane from a lane-held
+// copy 0.426 ms vs scalar loads 0.377; scalar loads prefetched one candidate ahead 0.406 (SGPR
+// pressure); IEEE division/sqrt +8 %; 32x32 macro-tiles 0.475, 8x8 single-wave workgroups 0.473;
+// 5 or 6 waves/SIMD = 4; a second slab level (1024-Gaussian groups) -12 % at 100 k Gaussians,
+// +3 % at 1 M; XCD-contiguous tile chunks 0.444 (centre-heavy scene: imbalance), row-striped
+// XCD map no gain; software-pipelining insertion(k) with the test of k+1 0.329.
 #ifndef RTGS_REC_MODE
-#define RTGS_REC_MODE 1   // 0: record held by a lane, broadcast with v_readlane; 1: scalar loads;
-#endif                    // 2: scalar loads prefetched one candidate ahead
-#ifndef RTGS_FILL_SKIP
-#define RTGS_FILL_SKIP 0  // stop the insertion bubble at the longest list of the wave
+#define RTGS_REC_MODE 1   // 1: scalar record loads where first needed; 3: whole record up front
 #endif
 #ifndef RTGS_INSERT
-#define RTGS_INSERT 1     // 0: compare/select bubble on 64-bit (t1,index) keys (7 VALU/level);
-#endif                    // 1: v_cmpx + v_swap_b32 under EXEC on 32-bit t1 keys (4 VALU/level)
+#define RTGS_INSERT 3     // 3: chain-free compare/select insertion; 1: v_cmpx/v_swap serial bubble
+#endif
 #ifndef RTGS_STAMPS
 #define RTGS_STAMPS 0     // diagnostic build: per-phase s_memtime stamps of wave 0 into the buffer
 #endif                    // passed as attenuation_buf (8 x u64 per block); never quote its run time
@@ -100,6 +97,7 @@ struct TraceArgs {
   float* att;
   float* start;
   int32_t start_stride;
+  const int32_t* tile_order;
 };
 
 // ------------------------------------------------------------------------------------
@@ -235,49 +233,39 @@ __global__ __launch_bounds__(256) void k_project(int32_t n, const float* __restr
 // ------------------------------------------------------------------------------------
 
 struct Rgb { float r, g, b; };
-struct Rec5 { float4 q[5]; };
-
-__device__ __forceinline__ float bcast(float v, int lane) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-}
-__device__ __forceinline__ float4 bcast4(const float4& v, int lane) {
-  return make_float4(bcast(v.x, lane), bcast(v.y, lane), bcast(v.z, lane), bcast(v.w, lane));
-}
-__device__ __forceinline__ Rec5 load_rec(const float4* __restrict__ rec, int gi) {
-  const float4* rp = rec + (size_t)gi * (kRecFloats / 4);
-  Rec5 r;
+// Per-lane list of the RTGS_MAX_DEPTH smallest entry distances: three register arrays (t1 bits,
+// Gaussian index, exponent), sorted ascending, empty slots = +inf.  Keys are the t1 bits alone
+// (t1 > 0, so unsigned order == float order); equal t1 keep their arrival order, which k_trace
+// makes deterministic (stream order).
+//
+// Insertion, chain-free form (default): the new key is compared with all 16 ORIGINAL slots at
+// once (independent compares; the results are monotone because the list is sorted), then every
+// slot picks its own value, its left neighbour's or the new element with two selects per field.
+// 112 VALU but no level depends on the previous one.  Measured against the alternatives on c3
+// (full frame / one-eighth shard): this 0.293 ms / 66 us; serial bubble with v_cmpx + v_swap_b32
+// under EXEC below (64 VALU, ~64 cycles of EXEC round trip per level even on an idle SIMD)
+// 0.301 / 85; select bubble on 64-bit (t1,index) keys 0.374; select bubble on 32-bit keys 0.372
+// / 94; v_med3_u32 for the keys 0.313 / 64; LDS append lists behind a front-to-back sort 1.21.
+__device__ __forceinline__ void list_insert_par(unsigned (&kt)[RTGS_MAX_DEPTH], unsigned (&ki)[RTGS_MAX_DEPTH],
+                                                float (&kw)[RTGS_MAX_DEPTH], unsigned tn, unsigned in,
+                                                float wn) {
+  bool lt[RTGS_MAX_DEPTH];
 #pragma unroll
-  for (int k = 0; k < 5; ++k) r.q[k] = rp[k];
-  return r;
-}
-
-// Sorted insert into the per-lane list of the RTGS_MAX_DEPTH smallest keys.  A key is
-// (t1 bits << 32 | Gaussian index): t1 > 0, so unsigned order == (t1, index) lexicographic
-// order, which makes the result independent of the order Gaussians arrive in.
-// `fill` (wave-uniform) bounds the number of valid entries of every lane's list: levels beyond
-// it hold only empty keys, so the bubble stops there.
-__device__ __forceinline__ void list_insert(unsigned long long (&key)[RTGS_MAX_DEPTH],
-                                            float (&wexp)[RTGS_MAX_DEPTH],
-                                            unsigned long long kn, float wn, int fill) {
+  for (int k = 0; k < RTGS_MAX_DEPTH; ++k) lt[k] = tn < kt[k];
 #pragma unroll
-  for (int k = 0; k < RTGS_MAX_DEPTH; ++k) {
-#if RTGS_FILL_SKIP
-    if (k > fill) break;  // wave-uniform
-#endif
-    const bool lt = kn < key[k];
-    const unsigned long long kk = key[k];
-    const float ww = wexp[k];
-    key[k] = lt ? kn : kk;
-    wexp[k] = lt ? wn : ww;
-    kn = lt ? kk : kn;
-    wn = lt ? ww : wn;
+  for (int k = RTGS_MAX_DEPTH - 1; k > 0; --k) {
+    kt[k] = lt[k - 1] ? kt[k - 1] : (lt[k] ? tn : kt[k]);
+    ki[k] = lt[k - 1] ? ki[k - 1] : (lt[k] ? in : ki[k]);
+    kw[k] = lt[k - 1] ? kw[k - 1] : (lt[k] ? wn : kw[k]);
   }
+  kt[0] = lt[0] ? tn : kt[0];
+  ki[0] = lt[0] ? in : ki[0];
+  kw[0] = lt[0] ? wn : kw[0];
 }
 
-// The same bubble with the hardware's conditional swap: v_cmpx narrows EXEC to the lanes whose
-// carried key is smaller, three v_swap_b32 exchange (t1, index, exponent) in those lanes only,
-// and EXEC is restored.  4 VALU + 1 SALU per level.  Keys are the t1 bits alone; equal t1 keep
-// their arrival order, which k_trace makes deterministic (stream order).
+// Alternative (RTGS_INSERT=1): serial bubble with the hardware's conditional swap: v_cmpx narrows
+// EXEC to the lanes whose carried key is smaller, three v_swap_b32 exchange the fields there,
+// EXEC is restored.  Fewest instructions, but every level waits for the previous one.
 #define RTGS_SWAP_LEVEL(k)                                                                 \
   asm volatile(                                                                            \
       "v_cmpx_lt_u32_e32 vcc, %0, %3\n\t"                                                   \
@@ -293,22 +281,11 @@ __device__ __forceinline__ void list_insert(unsigned long long (&key)[RTGS_MAX_D
 
 __device__ __forceinline__ void list_insert_swap(unsigned (&kt)[RTGS_MAX_DEPTH], unsigned (&ki)[RTGS_MAX_DEPTH],
                                                  float (&kw)[RTGS_MAX_DEPTH], unsigned tn, unsigned in,
-                                                 float wn, int fill) {
-  // `fill` (wave-uniform) = the longest list in the wave: slots above it are empty in every
-  // lane, and the carried element has been placed by then, so the bubble stops there.
+                                                 float wn) {
   const unsigned long long ex = __builtin_amdgcn_read_exec();
   RTGS_SWAP_LEVEL(0); RTGS_SWAP_LEVEL(1); RTGS_SWAP_LEVEL(2); RTGS_SWAP_LEVEL(3);
-#if RTGS_FILL_SKIP
-  if (fill < 4) return;
-#endif
   RTGS_SWAP_LEVEL(4); RTGS_SWAP_LEVEL(5); RTGS_SWAP_LEVEL(6); RTGS_SWAP_LEVEL(7);
-#if RTGS_FILL_SKIP
-  if (fill < 8) return;
-#endif
   RTGS_SWAP_LEVEL(8); RTGS_SWAP_LEVEL(9); RTGS_SWAP_LEVEL(10); RTGS_SWAP_LEVEL(11);
-#if RTGS_FILL_SKIP
-  if (fill < 12) return;
-#endif
   RTGS_SWAP_LEVEL(12); RTGS_SWAP_LEVEL(13); RTGS_SWAP_LEVEL(14); RTGS_SWAP_LEVEL(15);
 }
 
@@ -350,7 +327,8 @@ __global__ __launch_bounds__(kTraceBlock, RTGS_WAVES_PER_SIMD) void k_trace(cons
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
   const int wave = tid >> 6;
-  const int tile = a.tile_first + (int)blockIdx.x * a.tile_step;
+  const int ltile = a.tile_order ? a.tile_order[blockIdx.x] : (int)blockIdx.x;
+  const int tile = a.tile_first + ltile * a.tile_step;
   const int mi0 = (tile % a.tiles_x) * kTile;
   const int mj0 = (tile / a.tiles_x) * kTile;
   const int wi0 = mi0 + (wave % kWavesX) * kWaveTile;
@@ -382,28 +360,21 @@ __global__ __launch_bounds__(kTraceBlock, RTGS_WAVES_PER_SIMD) void k_trace(cons
   float start = 0.f;
   if ((a.flags & RTGS_TRACE_RESUME) && in_img) start = a.start[pix * a.start_stride];
 
-#if RTGS_INSERT == 0
-  unsigned long long key[RTGS_MAX_DEPTH];
-  constexpr unsigned long long kEmpty = 0x7F800000FFFFFFFFull;  // (+inf, -1)
-#else
   unsigned key[RTGS_MAX_DEPTH], kidx[RTGS_MAX_DEPTH];
   constexpr unsigned kEmpty = 0x7F800000u;  // +inf
-#endif
   float wexp[RTGS_MAX_DEPTH];
 #pragma unroll
   for (int k = 0; k < RTGS_MAX_DEPTH; ++k) {
     key[k] = kEmpty; wexp[k] = 0.f;
-#if RTGS_INSERT != 0
     kidx[k] = 0u;
-#endif
   }
-  int nvalid = 0;   // entries in this lane's list
-  int fill = 0;     // wave-uniform max of nvalid
 
   const unsigned long long lane_lt = (1ull << lane) - 1ull;
   const int nslabs = (a.n + kSlab - 1) / kSlab;
 #if RTGS_STAMPS
   unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
+  int c_iter = 0, c_hit = 0, c_ins = 0;
+  unsigned long long t_ins = 0, t_loop0 = 0, t_front = 0;
   st[0] = __builtin_amdgcn_s_memtime();
 #endif
   int scnt = 0;  // surviving slabs listed so far: identical in every thread
@@ -511,41 +482,22 @@ __global__ __launch_bounds__(kTraceBlock, RTGS_WAVES_PER_SIMD) void k_trace(cons
           asm volatile("" ::"s"(m));
           m = 0;
 #endif
-#if RTGS_REC_MODE == 0
-          float4 r0, r1, r2, r3, r4;
-          r0 = r1 = r2 = r3 = r4 = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (pass) {
-            const float4* rp = rec + (size_t)g * (kRecFloats / 4);
-            r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = rp[3]; r4 = rp[4];
-          }
-#elif RTGS_REC_MODE == 2
-          Rec5 nxt;
-          int gnext = 0;
-          if (m) {
-            gnext = __builtin_amdgcn_readlane(g, __builtin_ctzll(m));
-            nxt = load_rec(rec, gnext);
-          }
-#endif
           while (m) {
             const int b = __builtin_ctzll(m);
             m &= m - 1;
-#if RTGS_REC_MODE == 0
-            const int gi = __builtin_amdgcn_readlane(g, b);
-            const float4 q0 = bcast4(r0, b), q1 = bcast4(r1, b), q2 = bcast4(r2, b),
-                         q3 = bcast4(r3, b), q4 = bcast4(r4, b);
-#elif RTGS_REC_MODE == 1
+#if RTGS_STAMPS
+            ++c_iter;
+            t_loop0 = __builtin_amdgcn_s_memtime();
+#endif
             // the record's address is wave-uniform: scalar loads, operands straight from SGPRs
             const int gi = __builtin_amdgcn_readlane(g, b);
             const float4* rp = rec + (size_t)gi * (kRecFloats / 4);
             const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3], q4 = rp[4];
-#else
-            const int gi = gnext;
-            const Rec5 cur = nxt;
-            if (m) {
-              gnext = __builtin_amdgcn_readlane(g, __builtin_ctzll(m));
-              nxt = load_rec(rec, gnext);
-            }
-            const float4 q0 = cur.q[0], q1 = cur.q[1], q2 = cur.q[2], q3 = cur.q[3], q4 = cur.q[4];
+#if RTGS_REC_MODE == 3
+            // fetch the whole 80-B record before the first branch: one wait instead of three
+            asm volatile("" ::"s"(q0.x), "s"(q0.y), "s"(q0.z), "s"(q0.w), "s"(q1.x), "s"(q1.y), "s"(q1.z),
+                         "s"(q1.w), "s"(q2.x), "s"(q2.y), "s"(q2.z), "s"(q2.w), "s"(q3.x), "s"(q3.y),
+                         "s"(q3.z), "s"(q3.w), "s"(q4.x), "s"(q4.y));
 #endif
             // delta/4 = e_c + g.(x,y) - (x,y) P (x,y)^T about the record's expansion point
             const float x = X - q0.x;
@@ -557,6 +509,9 @@ __global__ __launch_bounds__(kTraceBlock, RTGS_WAVES_PER_SIMD) void k_trace(cons
             continue;
 #endif
             if (!__any(hit)) continue;
+#if RTGS_STAMPS
+            ++c_hit;
+#endif
             const float A = q2.x + q2.y * x + q2.z * y + (q2.w * x + q3.x * y) * x + (q3.y * y) * y;
             const float bq = q3.z + q3.w * x + q4.x * y;
             hit = hit && bq < 0.f;   // the cone half in front of the camera
@@ -569,14 +524,14 @@ __global__ __launch_bounds__(kTraceBlock, RTGS_WAVES_PER_SIMD) void k_trace(cons
             const float t1 = (q4.y / (sqrtf(e) - bq)) * dlen;
 #endif
             const bool cand = hit && t1 > start && t1 < kInf;  // scene.py:433
-#if RTGS_INSERT == 0
-            const unsigned long long kn =
-                cand ? (((unsigned long long)__float_as_uint(t1) << 32) | (unsigned)gi) : ~0ull;
-#else
             const unsigned kn = cand ? __float_as_uint(t1) : ~0u;
-#endif
             const bool ins = kn < key[RTGS_MAX_DEPTH - 1];
             if (__any(ins)) {
+#if RTGS_STAMPS
+              ++c_ins;
+              const unsigned long long ti0 = __builtin_amdgcn_s_memtime();
+              t_front += ti0 - t_loop0;
+#endif
 #if RTGS_FAST_DIV
               const float wn = e * __builtin_amdgcn_rcpf(A);
 #else
@@ -584,13 +539,14 @@ __global__ __launch_bounds__(kTraceBlock, RTGS_WAVES_PER_SIMD) void k_trace(cons
 #endif
 #if RTGS_ABLATE == 1
               asm volatile("" ::"v"(kn), "v"(wn));
-#elif RTGS_INSERT == 0
-              list_insert(key, wexp, kn, wn, fill);
+#elif RTGS_INSERT == 3
+              list_insert_par(key, kidx, wexp, kn, (unsigned)gi, wn);
 #else
-              list_insert_swap(key, kidx, wexp, kn, (unsigned)gi, wn, fill);
+              list_insert_swap(key, kidx, wexp, kn, (unsigned)gi, wn);
 #endif
-              if (__any(ins && nvalid == fill)) fill = min(fill + 1, RTGS_MAX_DEPTH - 1);
-              nvalid += (ins && nvalid < RTGS_MAX_DEPTH) ? 1 : 0;
+#if RTGS_STAMPS
+              t_ins += __builtin_amdgcn_s_memtime() - ti0;
+#endif
             }
           }
         }
@@ -631,13 +587,8 @@ __global__ __launch_bounds__(kTraceBlock, RTGS_WAVES_PER_SIMD) void k_trace(cons
 #pragma unroll
     for (int j = 0; j < kGroup; ++j) {
       const int k = k0 + j;
-#if RTGS_INSERT == 0
-      const unsigned tb = (unsigned)(key[k] >> 32);
-      const unsigned gi = (unsigned)(key[k] & 0xFFFFFFFFull);
-#else
       const unsigned tb = key[k];
       const unsigned gi = kidx[k];
-#endif
       cog[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (tb < 0x7F800000u) cog[j] = colop[gi];
     }
@@ -645,13 +596,8 @@ __global__ __launch_bounds__(kTraceBlock, RTGS_WAVES_PER_SIMD) void k_trace(cons
     for (int j = 0; j < kGroup; ++j) {
       const int k = k0 + j;
       if (k < a.depth && !done) {
-#if RTGS_INSERT == 0
-        const unsigned tbits = (unsigned)(key[k] >> 32);
-        const unsigned gi = (unsigned)(key[k] & 0xFFFFFFFFull);
-#else
         const unsigned tbits = key[k];
         const unsigned gi = kidx[k];
-#endif
         // an exact repeat of the previous entry distance is what the reference's strict
         // `t1 > ray.start` drops (scene.py:433 after ray_tracer.py:101)
         const bool valid = tbits < 0x7F800000u && tbits != prev_tbits;
@@ -683,7 +629,7 @@ __global__ __launch_bounds__(kTraceBlock, RTGS_WAVES_PER_SIMD) void k_trace(cons
   }
 
   if (a.flags & RTGS_TRACE_COMPACT) {
-    float* o = a.sample + ((size_t)blockIdx.x * kTile * kTile + (size_t)(pi - mi0) * kTile + (pj - mj0)) * 3;
+    float* o = a.sample + ((size_t)ltile * kTile * kTile + (size_t)(pi - mi0) * kTile + (pj - mj0)) * 3;
     *reinterpret_cast<Rgb*>(o) = Rgb{L0, L1, L2};   // one 12-B store per lane
   } else if (in_img) {
     float* o = a.sample + pix * 3;
@@ -698,6 +644,11 @@ __global__ __launch_bounds__(kTraceBlock, RTGS_WAVES_PER_SIMD) void k_trace(cons
   if (tid == 0 && a.att) {
     unsigned long long* sp = reinterpret_cast<unsigned long long*>(a.att) + (size_t)blockIdx.x * 8;
     for (int k = 0; k < 5; ++k) sp[k] = st[k];
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    sp[5] = (unsigned long long)c_iter | ((unsigned long long)c_hit << 16) | ((unsigned long long)c_ins << 32);
+    sp[6] = t_front; sp[7] = t_ins; (void)hwid; (void)xcc;
   }
 #endif
   if (in_img) {
@@ -813,6 +764,7 @@ int rtgs_trace(const RtgsScene* scene, const RtgsCamera* cam, const RtgsTracePar
   a.att = attenuation_buf;
   a.start = ray_start;
   a.start_stride = ray_start ? ray_start_stride : 1;
+  a.tile_order = params->tile_order;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (scene->sh)
     hipLaunchKernelGGL(k_trace<true>, dim3(local), dim3(kTraceBlock), 0, s, a, bbox, slab_bbox, rec, colop,

@@ -39,7 +39,7 @@ class RtgsCamera(Structure):
 
 class RtgsTraceParams(Structure):
     _fields_ = [("depth", c_int32), ("t_cutoff", c_float), ("tile_first", c_int32),
-                ("tile_step", c_int32), ("flags", c_uint32)]
+                ("tile_step", c_int32), ("flags", c_uint32), ("tile_order", c_void_p)]
 
 
 # name -> (restype, argtypes); mirrors include/rtgs_hip.h one to one.

@@ -48,7 +48,7 @@ class RayTracer:
         """One ``rtgs_trace`` launch on the current stream (see include/rtgs_hip.h)."""
         ws = self._ws()
         params = nat.RtgsTraceParams(int(depth), float(t_cutoff), int(tile_first), int(tile_step),
-                                     int(flags))
+                                     int(flags), None)
         out = self.sample_buf if sample_buf is None else nat.require_device(sample_buf, "sample_buf")
         rays = self.camera.cam_ray_field.data
         start_ptr = rays.data_ptr() + 6 * 4  # &cam_ray_field[0,0].start, stride 8 floats

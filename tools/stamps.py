@@ -22,7 +22,28 @@ for world in (1, 8):
         nat.check(nat.lib().rtgs_trace(scene.native(), camera.native(), params, nat.ptr(compact), stamps.data_ptr(),
                                        None, 1, nat.ptr(b.workspace), b.workspace.numel(), 1, nat.stream()))
     torch.cuda.synchronize()
-    s = stamps.cpu().numpy()[:, :5].astype(np.float64)
+    raw = stamps.cpu().numpy()
+    packed = raw[:, 5]
+    cnts = np.stack([packed & 0xFFFF, (packed >> 16) & 0xFFFF, (packed >> 32) & 0xFFFF], axis=1).astype(np.float64)
+    t_front, t_ins = raw[:, 6].astype(np.float64), raw[:, 7].astype(np.float64)
+    live_ = raw[:, 0] > 0
+    ni = np.maximum(cnts[:, 2], 1)
+    print(f"   inside the candidate loop (wave 0): front (load+test+hit path) {t_front[live_].sum()/cnts[live_,2].sum():.0f} cycles/insertion, "
+          f"insertion network {t_ins[live_].sum()/cnts[live_,2].sum():.0f} cycles/insertion")
+    hwid, xcc = raw[:, 6] * 0, raw[:, 7] * 0
+    cu, sh, se = (hwid >> 8) & 0xF, (hwid >> 12) & 1, (hwid >> 13) & 0x7
+    cuid = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+    if False:
+        print("   first 40 blocks (xcc,se,sh,cu):", [(int(xcc[i]), int(se[i]), int(sh[i]), int(cu[i])) for i in range(40)])
+        import collections
+        per_cu = collections.defaultdict(list)
+        for i in range(len(cuid)): per_cu[int(cuid[i])].append(i)
+        sizes = collections.Counter(len(v) for v in per_cu.values())
+        print("   distinct CUs:", len(per_cu), "WGs per CU histogram:", dict(sizes))
+        ex = list(per_cu.items())[:6]
+        print("   blocks sharing a CU (examples):", [v for _, v in ex])
+    s = raw[:, :5].astype(np.float64)
+    cnts = cnts[s[:, 0] > 0]
     s = s[s[:, 0] > 0]
     d = np.diff(s, axis=1)                      # scan, expand, process, composite
     t0 = s[:, 0].min()
@@ -31,6 +52,12 @@ for world in (1, 8):
     for k, nme in enumerate(names):
         print(f"   {nme:10s} mean {d[:,k].mean():9.0f}  p50 {np.median(d[:,k]):9.0f}  p95 {np.percentile(d[:,k],95):9.0f} ticks")
     life = s[:, 4] - s[:, 0]
+    proc = d[:, 2]
+    print(f"   wave 0 per WG: iterations mean {cnts[:,0].mean():.1f} max {cnts[:,0].max():.0f}; passed test {cnts[:,1].mean():.1f}; "
+          f"insertions {cnts[:,2].mean():.1f} max {cnts[:,2].max():.0f}; process cycles / insertion (sum/sum) {proc.sum()/max(cnts[:,2].sum(),1):.0f}")
+    heavy = proc > np.percentile(proc, 90)
+    print(f"   heaviest 10%: iterations {cnts[heavy,0].mean():.0f}, insertions {cnts[heavy,2].mean():.0f}, process {proc[heavy].mean():.0f} cycles "
+          f"=> {proc[heavy].sum()/cnts[heavy,2].sum():.0f} cycles/insertion")
     print(f"   lifetime   mean {life.mean():9.0f}  p50 {np.median(life):9.0f}  max {life.max():9.0f}; start spread {(s[:,0].max()-t0):.0f}")
     if world == 1:
         tx = (cfg.width + T - 1) // T
