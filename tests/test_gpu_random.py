@@ -50,3 +50,52 @@ def test_random_scene_and_camera(seed):
                                             f"{cam['width']}x{cam['height']}, depth {depth}")
     att = tracer.attenuation_buf.cpu().numpy().reshape(-1)
     assert np.abs(att - want["attenuation"])[solid].max() <= U.PIXEL_TOL
+
+
+@pytest.mark.parametrize("seed", [4001, 4003, 4005, 4006])
+def test_non_unit_quaternions_follow_the_reference_formulas(seed):
+    # Gaussian.init does not normalise rotation (gaussian.py:59-84) and quat.as_rotation_mat3 of a
+    # non-unit q is |q|^2 times a rotation (utils/quaternion.py:99-121); the same holds for the
+    # camera quaternion in rot_vec3 (camera.py:52).  The oracle restates those formulas literally.
+    arrays, cam, depth = random_case(seed)
+    rng = np.random.default_rng(seed)
+    arrays["rotation"] = (arrays["rotation"] * rng.uniform(0.7, 1.4, (arrays["rotation"].shape[0], 1))).astype(np.float32)
+    cam["rotation"] = scenes.f32_tuple(np.asarray(cam["rotation"]) * rng.uniform(0.8, 1.25))
+    _, _, tracer = U.build(arrays, cam)
+    tracer.sample_all(depth)
+    torch.cuda.synchronize()
+    want = c_oracle.render(arrays, cam, depth)
+    got = tracer.sample_buf.cpu().numpy().reshape(-1, 3)
+    err = np.abs(got - want["sample"]).max(axis=1)
+    solid = ~want["fragile"]
+    assert np.abs(want["sample"]).max() > 0.05 and solid.mean() >= 0.97
+    assert err[solid].max() <= U.PIXEL_TOL
+    # ray.start / hit distances are in units of the (non-unit) world direction, as in the reference
+    start = tracer.camera.cam_ray_field.start.cpu().numpy().reshape(-1)
+    fin = np.isfinite(want["start"]) & solid
+    assert (np.isfinite(start) == np.isfinite(want["start"]))[solid].all()
+    with np.errstate(invalid="ignore"):
+        assert np.abs(start - want["start"])[fin].max(initial=0.0) <= 2e-5 * max(1.0, np.abs(want["start"][fin]).max(initial=1.0))
+
+
+def test_non_finite_gaussians_are_culled():
+    # documented deviation: NaN / inf / zero-scale Gaussians never hit instead of
+    # poisoning pixels with NaN as the reference's arithmetic would
+    arrays, cam, depth = random_case(3001)
+    n = arrays["position"].shape[0]
+    clean = {k: (None if v is None else v.copy()) for k, v in arrays.items()}
+    bad = np.arange(0, n, 7)[:40]
+    arrays["position"][bad[0::4], 1] = np.nan
+    arrays["scale"][bad[1::4], 0] = np.inf
+    arrays["scale"][bad[2::4], 2] = 0.0
+    arrays["rotation"][bad[3::4]] = np.nan
+    keep = np.ones(n, bool)
+    keep[bad] = False
+    clean = {k: (None if v is None else np.ascontiguousarray(v[keep])) for k, v in clean.items()}
+    _, _, a = U.build(arrays, cam)
+    _, _, b = U.build(clean, cam)
+    a.sample_all(depth)
+    b.sample_all(depth)
+    torch.cuda.synchronize()
+    assert torch.isfinite(a.sample_buf).all()
+    assert float((a.sample_buf - b.sample_buf).abs().max()) <= 2e-6
