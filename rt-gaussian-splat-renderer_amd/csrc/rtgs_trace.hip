@@ -60,28 +60,29 @@ namespace {
 #ifndef RTGS_WAVES_PER_SIMD
 #define RTGS_WAVES_PER_SIMD 4   // __launch_bounds__ second argument: caps VGPRs at 512/this
 #endif
+#ifndef RTGS_WAVES_PER_SIMD_SH
+#define RTGS_WAVES_PER_SIMD_SH 4   // the SH variant carries 15 basis values more per lane
+#endif
 #ifndef RTGS_FAST_DIV
 #define RTGS_FAST_DIV 1   // v_rcp_f32 / v_sqrt_f32 (1 ulp) instead of IEEE division / sqrt
 #endif
 
 constexpr int kSlab = 64;                                 // Gaussians per slab = one wave
-#ifndef RTGS_SLAB_ITERS
-#define RTGS_SLAB_ITERS 2
-#endif
-#ifndef RTGS_SLABS_PER_WAVE
-#define RTGS_SLABS_PER_WAVE 2
-#endif
-#ifndef RTGS_COLOR_GROUP
-#define RTGS_COLOR_GROUP 4
-#endif
-constexpr int kSlabIters = kTraceBlock >= 1024 ? 1 : RTGS_SLAB_ITERS;  // slab bounds in flight per thread
-constexpr int kSlabStep = kSlabIters * kTraceBlock;       // slabs scanned per barrier
-constexpr int kSlabCap = 2048;                            // LDS list of surviving slabs
-constexpr int kSlabsPerWave = RTGS_SLABS_PER_WAVE;        // slabs one wave expands per batch
-constexpr int kBatch = kSlabsPerWave * kWavesPerTile;     // slabs expanded per batch
-constexpr int kListCap = kBatch * kSlab;                  // LDS list of surviving Gaussians
-static_assert(kBatch % kWavesPerTile == 0, "batch must split evenly over the waves");
-static_assert(kSlabCap >= 2 * kSlabStep || kSlabCap >= kSlabStep + 64, "slab list too small");
+// Batch sizes of the scan / expansion / colour-gather stages.  Measured optimum depends on the
+// number of slabs: c3 (1.6 k slabs) 2/2/4 -> 0.293 ms vs 0.344 with 4/4/8; c5 (15.6 k slabs, SH)
+// 4/4/8 -> 2.67 ms vs 3.11 with 2/2/4.  rtgs_trace picks the instantiation by scene size.
+template <bool kBig>
+struct Tune {
+  static constexpr int kSlabIters = kBig ? 4 : 2;           // slab bounds in flight per thread
+  static constexpr int kSlabStep = kSlabIters * kTraceBlock;  // slabs scanned per barrier
+  static constexpr int kSlabCap = 2048;                      // LDS list of surviving slabs
+  static constexpr int kSlabsPerWave = kBig ? 4 : 2;         // slabs one wave expands per batch
+  static constexpr int kBatch = kSlabsPerWave * kWavesPerTile;  // slabs expanded per batch
+  static constexpr int kListCap = kBatch * kSlab;            // LDS list of surviving Gaussians
+  static constexpr int kGroup = kBig ? 8 : 4;                // colour/opacity gathers in flight
+  static_assert(kSlabCap >= kSlabStep + 64, "slab list too small");
+};
+constexpr int kBigSceneSlabs = 4096;   // scenes with more slabs than this use Tune<true>
 
 struct TraceArgs {
   int32_t n;
@@ -311,13 +312,16 @@ __device__ __forceinline__ void sh_basis(float x, float y, float z, float (&Y)[R
   Y[14] = 0.25f * c3 * x * (x * x - 3.f * y * y);
 }
 
-template <bool kHasSh>
-__global__ __launch_bounds__(kTraceBlock, RTGS_WAVES_PER_SIMD) void k_trace(const TraceArgs a,
+template <bool kHasSh, bool kBig>
+__global__ __launch_bounds__(kTraceBlock, kHasSh ? RTGS_WAVES_PER_SIMD_SH : RTGS_WAVES_PER_SIMD) void k_trace(const TraceArgs a,
                                                           const float4* __restrict__ bbox,
                                                           const float4* __restrict__ slab_bbox,
                                                           const float4* __restrict__ rec,
                                                           const float4* __restrict__ colop,
                                                           const float* __restrict__ sh) {
+  using TN = Tune<kBig>;
+  constexpr int kSlabIters = TN::kSlabIters, kSlabStep = TN::kSlabStep, kSlabCap = TN::kSlabCap,
+                kSlabsPerWave = TN::kSlabsPerWave, kBatch = TN::kBatch, kListCap = TN::kListCap;
   __shared__ int s_slab[kSlabCap];
   __shared__ float4 s_bb[kListCap];
   __shared__ int s_idx[kListCap];
@@ -578,7 +582,7 @@ __global__ __launch_bounds__(kTraceBlock, RTGS_WAVES_PER_SIMD) void k_trace(cons
   int nhit = 0;
   float last_t = 0.f;
   unsigned prev_tbits = 0u;
-  constexpr int kGroup = RTGS_COLOR_GROUP;   // colour/opacity gathers issued together
+  constexpr int kGroup = TN::kGroup;   // colour/opacity gathers issued together
   bool done = false;
 #pragma unroll
   for (int k0 = 0; k0 < RTGS_MAX_DEPTH; k0 += kGroup) {
@@ -766,12 +770,14 @@ int rtgs_trace(const RtgsScene* scene, const RtgsCamera* cam, const RtgsTracePar
   a.start_stride = ray_start ? ray_start_stride : 1;
   a.tile_order = params->tile_order;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (scene->sh)
-    hipLaunchKernelGGL(k_trace<true>, dim3(local), dim3(kTraceBlock), 0, s, a, bbox, slab_bbox, rec, colop,
-                       scene->sh);
-  else
-    hipLaunchKernelGGL(k_trace<false>, dim3(local), dim3(kTraceBlock), 0, s, a, bbox, slab_bbox, rec, colop,
-                       static_cast<const float*>(nullptr));
+  const bool big = (scene->n + kSlab - 1) / kSlab > kBigSceneSlabs;
+  const float* sh = scene->sh;
+#define RTGS_LAUNCH(HAS_SH, BIG)                                                                  \
+  hipLaunchKernelGGL((k_trace<HAS_SH, BIG>), dim3(local), dim3(kTraceBlock), 0, s, a, bbox, slab_bbox, \
+                     rec, colop, sh)
+  if (sh) { if (big) RTGS_LAUNCH(true, true); else RTGS_LAUNCH(true, false); }
+  else    { if (big) RTGS_LAUNCH(false, true); else RTGS_LAUNCH(false, false); }
+#undef RTGS_LAUNCH
   return check_launch();
 }
 

@@ -99,3 +99,22 @@ def test_non_finite_gaussians_are_culled():
     torch.cuda.synchronize()
     assert torch.isfinite(a.sample_buf).all()
     assert float((a.sample_buf - b.sample_buf).abs().max()) <= 2e-6
+
+
+@pytest.mark.parametrize("sh", [False, True])
+def test_large_scene_instantiation(sh):
+    # more than 4096 slabs (262 144 Gaussians) selects the large-batch instantiation of the
+    # trace kernel (Tune<true> in csrc/rtgs_trace.hip); sampled pixels vs the C oracle
+    n, w, h = 280_000, 320, 180
+    arrays = synthetic.make_scene(n, w / h, 5150, sh=sh)
+    cam = synthetic.bench_camera(w, h)
+    cam["rotation"] = scenes.quat_axis_angle((0.2, 1.0, 0.0), 0.2)
+    _, _, tracer = U.build(arrays, cam)
+    tracer.sample_all(16)
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(1)
+    pix = np.stack([rng.integers(0, w, 3000), rng.integers(0, h, 3000)], axis=-1).astype(np.int32)
+    want = c_oracle.render(arrays, cam, 16, pix)
+    worst = U.assert_parity(U.at(tracer.sample_buf, pix), want, f"large scene sh={sh}")
+    assert want["hits"].mean() > 8
+    print(f"large scene sh={sh}: max |err| {worst:.2e}")
