@@ -247,14 +247,14 @@ struct Rgb { float r, g, b; };
 // under EXEC below (64 VALU, ~64 cycles of EXEC round trip per level even on an idle SIMD)
 // 0.301 / 85; select bubble on 64-bit (t1,index) keys 0.374; select bubble on 32-bit keys 0.372
 // / 94; v_med3_u32 for the keys 0.313 / 64; LDS append lists behind a front-to-back sort 1.21.
-__device__ __forceinline__ void list_insert_par(unsigned (&kt)[RTGS_MAX_DEPTH], unsigned (&ki)[RTGS_MAX_DEPTH],
-                                                float (&kw)[RTGS_MAX_DEPTH], unsigned tn, unsigned in,
-                                                float wn) {
-  bool lt[RTGS_MAX_DEPTH];
+template <int kK>
+__device__ __forceinline__ void list_insert_par(unsigned (&kt)[kK], unsigned (&ki)[kK], float (&kw)[kK],
+                                                unsigned tn, unsigned in, float wn) {
+  bool lt[kK];
 #pragma unroll
-  for (int k = 0; k < RTGS_MAX_DEPTH; ++k) lt[k] = tn < kt[k];
+  for (int k = 0; k < kK; ++k) lt[k] = tn < kt[k];
 #pragma unroll
-  for (int k = RTGS_MAX_DEPTH - 1; k > 0; --k) {
+  for (int k = kK - 1; k > 0; --k) {
     kt[k] = lt[k - 1] ? kt[k - 1] : (lt[k] ? tn : kt[k]);
     ki[k] = lt[k - 1] ? ki[k - 1] : (lt[k] ? in : ki[k]);
     kw[k] = lt[k - 1] ? kw[k - 1] : (lt[k] ? wn : kw[k]);
@@ -312,7 +312,9 @@ __device__ __forceinline__ void sh_basis(float x, float y, float z, float (&Y)[R
   Y[14] = 0.25f * c3 * x * (x * x - 3.f * y * y);
 }
 
-template <bool kHasSh, bool kBig>
+// kK = list length: RTGS_MAX_DEPTH, or 1 for single-peel calls (the reference viewer's one
+// sample_step per frame), where the list degenerates to "the nearest hit so far".
+template <bool kHasSh, bool kBig, int kK>
 __global__ __launch_bounds__(kTraceBlock, kHasSh ? RTGS_WAVES_PER_SIMD_SH : RTGS_WAVES_PER_SIMD) void k_trace(const TraceArgs a,
                                                           const float4* __restrict__ bbox,
                                                           const float4* __restrict__ slab_bbox,
@@ -364,11 +366,11 @@ __global__ __launch_bounds__(kTraceBlock, kHasSh ? RTGS_WAVES_PER_SIMD_SH : RTGS
   float start = 0.f;
   if ((a.flags & RTGS_TRACE_RESUME) && in_img) start = a.start[pix * a.start_stride];
 
-  unsigned key[RTGS_MAX_DEPTH], kidx[RTGS_MAX_DEPTH];
+  unsigned key[kK], kidx[kK];
   constexpr unsigned kEmpty = 0x7F800000u;  // +inf
-  float wexp[RTGS_MAX_DEPTH];
+  float wexp[kK];
 #pragma unroll
-  for (int k = 0; k < RTGS_MAX_DEPTH; ++k) {
+  for (int k = 0; k < kK; ++k) {
     key[k] = kEmpty; wexp[k] = 0.f;
     kidx[k] = 0u;
   }
@@ -529,7 +531,7 @@ __global__ __launch_bounds__(kTraceBlock, kHasSh ? RTGS_WAVES_PER_SIMD_SH : RTGS
 #endif
             const bool cand = hit && t1 > start && t1 < kInf;  // scene.py:433
             const unsigned kn = cand ? __float_as_uint(t1) : ~0u;
-            const bool ins = kn < key[RTGS_MAX_DEPTH - 1];
+            const bool ins = kn < key[kK - 1];
             if (__any(ins)) {
 #if RTGS_STAMPS
               ++c_ins;
@@ -546,7 +548,8 @@ __global__ __launch_bounds__(kTraceBlock, kHasSh ? RTGS_WAVES_PER_SIMD_SH : RTGS
 #elif RTGS_INSERT == 3
               list_insert_par(key, kidx, wexp, kn, (unsigned)gi, wn);
 #else
-              list_insert_swap(key, kidx, wexp, kn, (unsigned)gi, wn);
+              if constexpr (kK == RTGS_MAX_DEPTH) list_insert_swap(key, kidx, wexp, kn, (unsigned)gi, wn);
+              else list_insert_par(key, kidx, wexp, kn, (unsigned)gi, wn);
 #endif
 #if RTGS_STAMPS
               t_ins += __builtin_amdgcn_s_memtime() - ti0;
@@ -582,10 +585,10 @@ __global__ __launch_bounds__(kTraceBlock, kHasSh ? RTGS_WAVES_PER_SIMD_SH : RTGS
   int nhit = 0;
   float last_t = 0.f;
   unsigned prev_tbits = 0u;
-  constexpr int kGroup = TN::kGroup;   // colour/opacity gathers issued together
+  constexpr int kGroup = TN::kGroup < kK ? TN::kGroup : kK;   // colour/opacity gathers issued together
   bool done = false;
 #pragma unroll
-  for (int k0 = 0; k0 < RTGS_MAX_DEPTH; k0 += kGroup) {
+  for (int k0 = 0; k0 < kK; k0 += kGroup) {
     if (k0 >= a.depth || done) break;
     float4 cog[kGroup];
 #pragma unroll
@@ -772,11 +775,14 @@ int rtgs_trace(const RtgsScene* scene, const RtgsCamera* cam, const RtgsTracePar
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool big = (scene->n + kSlab - 1) / kSlab > kBigSceneSlabs;
   const float* sh = scene->sh;
-#define RTGS_LAUNCH(HAS_SH, BIG)                                                                  \
-  hipLaunchKernelGGL((k_trace<HAS_SH, BIG>), dim3(local), dim3(kTraceBlock), 0, s, a, bbox, slab_bbox, \
-                     rec, colop, sh)
-  if (sh) { if (big) RTGS_LAUNCH(true, true); else RTGS_LAUNCH(true, false); }
-  else    { if (big) RTGS_LAUNCH(false, true); else RTGS_LAUNCH(false, false); }
+#define RTGS_LAUNCH(HAS_SH, BIG, K)                                                                \
+  hipLaunchKernelGGL((k_trace<HAS_SH, BIG, K>), dim3(local), dim3(kTraceBlock), 0, s, a, bbox,        \
+                     slab_bbox, rec, colop, sh)
+#define RTGS_LAUNCH_K(HAS_SH, BIG) \
+  do { if (params->depth == 1) RTGS_LAUNCH(HAS_SH, BIG, 1); else RTGS_LAUNCH(HAS_SH, BIG, RTGS_MAX_DEPTH); } while (0)
+  if (sh) { if (big) RTGS_LAUNCH_K(true, true); else RTGS_LAUNCH_K(true, false); }
+  else    { if (big) RTGS_LAUNCH_K(false, true); else RTGS_LAUNCH_K(false, false); }
+#undef RTGS_LAUNCH_K
 #undef RTGS_LAUNCH
   return check_launch();
 }

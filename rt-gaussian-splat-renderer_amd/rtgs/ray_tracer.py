@@ -34,6 +34,7 @@ class RayTracer:
         self.num_samples = 0
         self.disp_buf = torch.zeros((w, h, 3), dtype=torch.float32, device=dev)
         self._workspace = None
+        self._projected_for = None   # (scene version, camera pose) the workspace records belong to
 
     # ---- plumbing ------------------------------------------------------------------------
     def _ws(self) -> torch.Tensor:
@@ -49,6 +50,16 @@ class RayTracer:
         ws = self._ws()
         params = nat.RtgsTraceParams(int(depth), float(t_cutoff), int(tile_first), int(tile_step),
                                      int(flags), None)
+        # the per-frame projection only depends on (scene, camera pose): the 16 single-peel calls of
+        # one progressive sample share it
+        pos = self.camera.position if position is None else position
+        rot = self.camera.rotation if rotation is None else rotation
+        state = (id(self.scene), self.scene.version, ws.data_ptr(),
+                 tuple(float(v) for v in pos), tuple(float(v) for v in rot),
+                 tuple(float(v) for v in self.camera.focal_length))
+        if not projected and state == self._projected_for:
+            projected = True
+        self._projected_for = state
         out = self.sample_buf if sample_buf is None else nat.require_device(sample_buf, "sample_buf")
         rays = self.camera.cam_ray_field.data
         start_ptr = rays.data_ptr() + 6 * 4  # &cam_ray_field[0,0].start, stride 8 floats

@@ -110,6 +110,7 @@ class Scene:
         self.gaussian_field = None  # scene.py:83 allocates a shape-() field; filled by load
         self.num_gaussians = 0
         self.position = self.cov_inv6 = self.color_opacity = self.sh = None
+        self.version = 0            # bumped by commit(): invalidates cached projections
         self.order = None           # stream slot -> index into gaussian_field
         self.sort_spatially = True  # Morton-order the streamed copies (see morton_order)
 
@@ -154,6 +155,7 @@ class Scene:
         if n <= 0:
             raise ValueError("scene has no Gaussians")
         self.num_gaussians = n
+        self.version += 1
         dev = f.position.device
         if self.sort_spatially and n > 64:
             self.order = morton_order(f.position)

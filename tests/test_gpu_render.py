@@ -330,3 +330,29 @@ def test_tile_parallel_frame_loop_end_to_end(world):
     torch.cuda.synchronize()
     assert torch.equal(ranks[0].framebuffer, whole)
     assert all(r.framebuffer is None for r in ranks[1:])
+
+
+def test_single_peel_calls_reuse_the_projection_and_track_scene_changes():
+    # sample() x depth projects once (camera unchanged) yet must notice a new camera pose or a
+    # re-committed scene
+    arrays, cam, depth = U.case("c1")
+    scene, camera, tracer = U.build(arrays, cam)
+    for _ in range(depth):
+        tracer.sample(depth)
+    first = tracer.sample_buf.clone()
+    camera.position = rtgs.utils.types.vec3(0.2, 0.1, 3.0)          # move the camera
+    tracer.clear_sample()
+    for _ in range(depth):
+        tracer.sample(depth)
+    moved = tracer.sample_buf.clone()
+    assert float((moved - first).abs().max()) > 1e-2
+    _, cam2_, ref_tr = U.build(arrays, dict(cam, position=(0.2, 0.1, 3.0)))
+    ref_tr.sample_all(depth)
+    assert float((moved - ref_tr.sample_buf).abs().max()) <= 2e-6
+    scene.gaussian_field.color[:] = 0.25                              # edit the scene in place
+    scene.commit()
+    tracer.clear_sample()
+    for _ in range(depth):
+        tracer.sample(depth)
+    assert float((tracer.sample_buf - moved).abs().max()) > 1e-2
+    assert float(tracer.sample_buf.max()) <= 0.25 + 1e-6
