@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RTGS_ABI_VERSION 1
+#define RTGS_ABI_VERSION 2
 #define RTGS_MAX_DEPTH 16        /* peels kept per ray in one pass (__main__.py:70 default) */
 #ifndef RTGS_TILE
 #define RTGS_TILE 16             /* macro-tile edge in pixels: one workgroup, the unit of sharding */
@@ -52,11 +52,14 @@ typedef void* rtgs_stream_t;
 
 /* Gaussians, structure-of-arrays in HBM.  Values are post-activation, i.e. exactly what
  * Gaussian.init takes (gaussian.py:59-84): what Scene.load_file produces at scene.py:110-114. */
+/* The kernels rebuild Sigma^-1 = R S^-2 R^T in fp64 from (rotation, scale) wherever they need it:
+ * an inverse covariance ROUNDED to fp32 moves delta/(4A) by ~2e-4 for a 70:1 needle Gaussian,
+ * enough to flip grazing hits against the fp64 oracle (found by tools/fuzz_gpu.py). */
 typedef struct RtgsScene {
   int32_t n;
   const float* position;      /* [n][3]  Gaussian.position                         */
-  const float* cov_inv6;      /* [n][6]  inverse covariance xx,xy,xz,yy,yz,zz      */
-                              /*         (rtgs_covariance output)                  */
+  const float* rotation;      /* [n][4]  Gaussian.rotation, xyzw                   */
+  const float* scale;         /* [n][3]  Gaussian.scale                            */
   const float* color_opacity; /* [n][4]  Gaussian.color rgb, Gaussian.opacity      */
   const float* sh;            /* [n][15][3] sh_10..sh_36, or NULL (all zero)       */
 } RtgsScene;
@@ -96,7 +99,8 @@ const char* rtgs_strerror(int code);
 
 /* Gaussian.cov (gaussian.py:86-102) with quat.as_rotation_mat3 (utils/quaternion.py:99-121):
  * Sigma = R S S^T R^T per Gaussian, and its inverse (the ti.math.inverse of gaussian.py:196,215,
- * evaluated as R S^-2 R^T).  cov6 may be NULL.  Layout xx,xy,xz,yy,yz,zz. */
+ * evaluated as R S^-2 R^T), rounded to fp32 for the caller.  cov6 may be NULL.  Layout
+ * xx,xy,xz,yy,yz,zz.  (The render kernels do not consume this output: see RtgsScene.) */
 int rtgs_covariance(int32_t n, const float* rotation /*[n][4]*/, const float* scale /*[n][3]*/,
                     float* cov6 /*[n][6] or NULL*/, float* cov_inv6 /*[n][6]*/,
                     rtgs_stream_t stream);
@@ -150,14 +154,15 @@ int rtgs_closest_hit(const RtgsScene* scene, int32_t n_rays, const float* rays,
 
 /* Gaussian.hit (gaussian.py:203-230), elementwise: ray k against Gaussian k. */
 int rtgs_gaussian_hit(int32_t n, const float* rays /*[n][8]*/, const float* position /*[n][3]*/,
-                      const float* cov_inv6 /*[n][6]*/, float* hit_t /*[n][2]*/,
-                      rtgs_stream_t stream);
+                      const float* rotation /*[n][4]*/, const float* scale /*[n][3]*/,
+                      float* hit_t /*[n][2]*/, rtgs_stream_t stream);
 
 /* Gaussian.eval (gaussian.py:183-201) incl. eval_sh (gaussian.py:140-181), elementwise:
  * out[k] = (rgb, alpha) of Gaussian k at pos[k] seen along dir[k].  sh may be NULL. */
 int rtgs_gaussian_eval(int32_t n, const float* pos /*[n][3]*/, const float* dir /*[n][3]*/,
-                       const float* position, const float* cov_inv6, const float* color_opacity,
-                       const float* sh, float* out /*[n][4]*/, rtgs_stream_t stream);
+                       const float* position, const float* rotation, const float* scale,
+                       const float* color_opacity, const float* sh, float* out /*[n][4]*/,
+                       rtgs_stream_t stream);
 
 /* quat.mul / conj / rot_vec3 / as_rotation_mat3 (utils/quaternion.py:8-35, 84-121), batched.
  * op: 0 mul(p,q)->[n][4]; 1 conj(p)->[n][4]; 2 rot_vec3(p, q.xyz)->[n][3];

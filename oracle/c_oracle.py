@@ -31,7 +31,7 @@ def _f32(a):
     return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
 
 
-def render(arrays: dict, cam: dict, depth: int, pixels=None, eps_q=1e-5, eps_t=3e-6) -> dict:
+def render(arrays: dict, cam: dict, depth: int, pixels=None, eps_q=1e-5, eps_t=1e-6) -> dict:
     """fp64 one-pass render of `pixels` ((n,2) int (i,j); default: the whole (W,H) frame, i major).
     Same return keys as rtgs_ref.render_topk (sample, attenuation, start, hits, margins, fragile)."""
     lib = _load()

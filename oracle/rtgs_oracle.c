@@ -145,8 +145,10 @@ int rtgs_oracle_render(int n, const float* pos, const float* rot, const float* s
       const double dn[3] = {d[0] / l2, d[1] / l2, d[2] / l2}; /* gaussian.py:200 */
       sh_basis(dn, Y);
     }
-    for (int k = 0; k + 1 < K; ++k)
-      if (isfinite(kt[k + 1]) && kt[k + 1] - kt[k] < mt) mt = kt[k + 1] - kt[k];
+    for (int k = 0; k + 1 < K; ++k) { /* gap relative to max(1, t1): fp32 error of t1 grows with t1 */
+      const double gap = (kt[k + 1] - kt[k]) / fmax(1.0, kt[k + 1]);
+      if (isfinite(kt[k + 1]) && gap < mt) mt = gap;
+    }
     for (int k = 0; k < K - 1 && nh < depth; ++k) {
       if (!isfinite(kt[k])) break;
       if (kt[k] == prev) continue;

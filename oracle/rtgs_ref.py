@@ -433,7 +433,7 @@ def render_peel(scene, cam_position, cam_rotation, width, height, fx, fy, depth=
 
 
 def render_topk(scene, cam_position, cam_rotation, width, height, fx, fy, depth=16,
-                pixels=None, chunk=None, eps_q=1e-5, eps_t=3e-6):
+                pixels=None, chunk=None, eps_q=1e-5, eps_t=1e-6):
     """SURVEY.md Appendix A.9 -- the one-pass form of the same image: the <= depth Gaussians
     with the smallest entry distance t1 > 0, sorted ascending, composited front to back, with
     alpha = opacity * exp(delta/(4A) - 3) (== the chord-midpoint evaluation of gaussian.py:197).
@@ -441,7 +441,8 @@ def render_topk(scene, cam_position, cam_rotation, width, height, fx, fy, depth=
     Also reports, per pixel, how close the result is to a discontinuity of the image function
     (a grazing hit, or two entry distances about to swap / cross the depth cut):
       margin_q = min |delta/(4A)| over Gaussians in front of the camera,
-      margin_t = min gap between consecutive sorted t1 among the first depth+1 hits.
+      margin_t = min gap between consecutive sorted t1 among the first depth+1 hits, relative
+                 to max(1, t1) (an fp32 t1 carries a few ulp of error, which grows with t1).
     `fragile` = margin_q < eps_q or margin_t < eps_t: an fp32 renderer may legitimately take
     the other branch there.
     """
@@ -496,7 +497,7 @@ def render_topk(scene, cam_position, cam_rotation, width, height, fx, fy, depth=
         hits[h] += 1
         last_t[h] = keep_t[h, k]
     with np.errstate(invalid="ignore"):
-        gaps = np.diff(keep_t, axis=1)
+        gaps = np.diff(keep_t, axis=1) / np.maximum(1.0, keep_t[:, 1:])
     gaps = np.where(np.isfinite(keep_t[:, 1:]), gaps, np.inf)
     margin_t = np.min(gaps, axis=1) if K > 1 else np.full(n, np.inf)
     start = np.where(hits == depth, last_t, np.inf).astype(dt)

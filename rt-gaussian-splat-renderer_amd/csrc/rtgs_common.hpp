@@ -61,6 +61,23 @@ __host__ __device__ inline void quat_to_mat3(const T* q, T* m) {
   m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x); m[8] = s + 2 * z * z;
 }
 
+// gaussian.py:86-102 + ti.math.inverse (gaussian.py:196,215): Sigma^-1 = R S^-2 R^T / |q|^8, because
+// the reference's R is |q|^2 times a rotation.  fp64, from the fp32 quaternion and scale.
+// m6 = xx, xy, xz, yy, yz, zz.
+__host__ __device__ inline void cov_inverse6(const float* rot, const float* scale, double* m6) {
+  const double q[4] = {rot[0], rot[1], rot[2], rot[3]};
+  double R[9];
+  quat_to_mat3(q, R);
+  const double k2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  const double k8 = (k2 * k2) * (k2 * k2);
+  const double i0 = 1.0 / ((double)scale[0] * scale[0] * k8), i1 = 1.0 / ((double)scale[1] * scale[1] * k8),
+               i2 = 1.0 / ((double)scale[2] * scale[2] * k8);
+  int o = 0;
+  for (int i = 0; i < 3; ++i)
+    for (int j = i; j < 3; ++j)
+      m6[o++] = R[3 * i] * i0 * R[3 * j] + R[3 * i + 1] * i1 * R[3 * j + 1] + R[3 * i + 2] * i2 * R[3 * j + 2];
+}
+
 // Per-frame camera constants, computed on the host in fp64 from the fp32 RtgsCamera.
 struct FrameCam {
   double o[3];        // camera position

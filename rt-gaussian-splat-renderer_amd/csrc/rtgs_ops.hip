@@ -72,8 +72,9 @@ __global__ __launch_bounds__(256) void k_generate_rays(RtgsCamera cam, float* __
 // ---- ray/ellipsoid quadratic, gaussian.py:203-230, fp64 inside -------------------------
 struct HitD { double t1, t2; };
 
+template <typename TM>
 __device__ __forceinline__ HitD hit_quadratic(const double o[3], const double d[3], const float* mu,
-                                              const float* ci) {
+                                              const TM* ci) {
   const double inf = __builtin_huge_val();
   const double mx = o[0] - (double)mu[0], my = o[1] - (double)mu[1], mz = o[2] - (double)mu[2];
   const double Mxx = ci[0], Mxy = ci[1], Mxz = ci[2], Myy = ci[3], Myz = ci[4], Mzz = ci[5];
@@ -99,16 +100,18 @@ __device__ __forceinline__ HitD hit_quadratic(const double o[3], const double d[
 }
 
 // ---- Scene.hit for a batch of arbitrary rays (scene.py:406-450) ------------------------
-// One thread per ray; the workgroup streams (position, inverse covariance) = 36 B/Gaussian
-// through LDS in slabs.  Brute force: the BVH of the reference only accelerates this query.
+// One thread per ray; the workgroup streams (position, rotation, scale) = 40 B/Gaussian, builds
+// each slab's inverse covariances in fp64 and keeps the slab in LDS.  Brute force: the BVH of the reference only accelerates this query.
 constexpr int kHitBlock = 256;
 __global__ __launch_bounds__(kHitBlock) void k_closest_hit(int32_t n, const float* __restrict__ pos,
-                                                            const float* __restrict__ ci6,
+                                                            const float* __restrict__ rot,
+                                                            const float* __restrict__ scale,
                                                             int32_t n_rays,
                                                             const float* __restrict__ rays,
                                                             int32_t* __restrict__ hit_idx,
                                                             float* __restrict__ hit_t) {
-  __shared__ float s_g[kHitBlock * 9];
+  __shared__ float s_mu[kHitBlock * 3];
+  __shared__ double s_m[kHitBlock * 6];   // inverse covariances of the slab, built here in fp64
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = r < n_rays;
   double o[3] = {0, 0, 0}, d[3] = {0, 1, 0};
@@ -127,16 +130,14 @@ __global__ __launch_bounds__(kHitBlock) void k_closest_hit(int32_t n, const floa
     __syncthreads();
     if ((int)threadIdx.x < cnt) {
       const int g = base + threadIdx.x;
-      float* s = s_g + threadIdx.x * 9;
+      float* s = s_mu + threadIdx.x * 3;
       s[0] = pos[3 * g]; s[1] = pos[3 * g + 1]; s[2] = pos[3 * g + 2];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) s[3 + k] = ci6[6 * g + k];
+      cov_inverse6(rot + 4 * (size_t)g, scale + 3 * (size_t)g, s_m + threadIdx.x * 6);
     }
     __syncthreads();
     if (live) {
       for (int k = 0; k < cnt; ++k) {
-        const float* s = s_g + k * 9;
-        const HitD h = hit_quadratic(o, d, s, s + 3);
+        const HitD h = hit_quadratic(o, d, s_mu + k * 3, s_m + k * 6);
         // scene.py:433-436: start < t1 < end, strictly smaller than the best so far
         if (h.t1 < (double)end && h.t1 > (double)start && h.t1 < best_t) {
           best_t = h.t1; best_t2 = h.t2; best = base + k;
@@ -154,14 +155,17 @@ __global__ __launch_bounds__(kHitBlock) void k_closest_hit(int32_t n, const floa
 // ---- Gaussian.hit, elementwise ----------------------------------------------------------
 __global__ __launch_bounds__(256) void k_gaussian_hit(int32_t n, const float* __restrict__ rays,
                                                        const float* __restrict__ pos,
-                                                       const float* __restrict__ ci6,
+                                                       const float* __restrict__ rot,
+                                                       const float* __restrict__ scale,
                                                        float* __restrict__ hit_t) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   const float* rp = rays + (size_t)k * RTGS_RAY_FLOATS;
   const double o[3] = {rp[0], rp[1], rp[2]};
   const double d[3] = {rp[3], rp[4], rp[5]};
-  const HitD h = hit_quadratic(o, d, pos + 3 * (size_t)k, ci6 + 6 * (size_t)k);
+  double m6[6];
+  cov_inverse6(rot + 4 * (size_t)k, scale + 3 * (size_t)k, m6);
+  const HitD h = hit_quadratic(o, d, pos + 3 * (size_t)k, m6);
   hit_t[2 * k] = (float)h.t1;
   hit_t[2 * k + 1] = (float)h.t2;
 }
@@ -170,7 +174,8 @@ __global__ __launch_bounds__(256) void k_gaussian_hit(int32_t n, const float* __
 __global__ __launch_bounds__(256) void k_gaussian_eval(int32_t n, const float* __restrict__ pos,
                                                         const float* __restrict__ dir,
                                                         const float* __restrict__ mu,
-                                                        const float* __restrict__ ci6,
+                                                        const float* __restrict__ rot,
+                                                        const float* __restrict__ scale,
                                                         const float* __restrict__ colop,
                                                         const float* __restrict__ sh,
                                                         float* __restrict__ out) {
@@ -178,7 +183,8 @@ __global__ __launch_bounds__(256) void k_gaussian_eval(int32_t n, const float* _
   if (k >= n) return;
   const double x = (double)pos[3 * k] - mu[3 * k], y = (double)pos[3 * k + 1] - mu[3 * k + 1],
                z = (double)pos[3 * k + 2] - mu[3 * k + 2];
-  const float* c = ci6 + 6 * (size_t)k;
+  double c[6];
+  cov_inverse6(rot + 4 * (size_t)k, scale + 3 * (size_t)k, c);
   const double q = x * (c[0] * x + c[1] * y + c[2] * z) + y * (c[1] * x + c[3] * y + c[4] * z) +
                    z * (c[2] * x + c[4] * y + c[5] * z);
   const double rho = exp(-q);  // no 1/2 factor: gaussian.py:197
@@ -298,28 +304,28 @@ int rtgs_generate_rays(const RtgsCamera* cam, float* rays, rtgs_stream_t stream)
 
 int rtgs_closest_hit(const RtgsScene* scene, int32_t n_rays, const float* rays, int32_t* hit_idx,
                      float* hit_t, rtgs_stream_t stream) {
-  if (!scene || scene->n <= 0 || !scene->position || !scene->cov_inv6) return RTGS_EINVAL;
+  if (!scene || scene->n <= 0 || !scene->position || !scene->rotation || !scene->scale) return RTGS_EINVAL;
   if (n_rays <= 0 || !rays || !hit_idx || !hit_t) return RTGS_EINVAL;
   hipLaunchKernelGGL(k_closest_hit, grid_for(n_rays, kHitBlock), dim3(kHitBlock), 0,
-                     static_cast<hipStream_t>(stream), scene->n, scene->position, scene->cov_inv6,
-                     n_rays, rays, hit_idx, hit_t);
+                     static_cast<hipStream_t>(stream), scene->n, scene->position, scene->rotation,
+                     scene->scale, n_rays, rays, hit_idx, hit_t);
   return check_launch();
 }
 
-int rtgs_gaussian_hit(int32_t n, const float* rays, const float* position, const float* cov_inv6,
-                      float* hit_t, rtgs_stream_t stream) {
-  if (n <= 0 || !rays || !position || !cov_inv6 || !hit_t) return RTGS_EINVAL;
+int rtgs_gaussian_hit(int32_t n, const float* rays, const float* position, const float* rotation,
+                      const float* scale, float* hit_t, rtgs_stream_t stream) {
+  if (n <= 0 || !rays || !position || !rotation || !scale || !hit_t) return RTGS_EINVAL;
   hipLaunchKernelGGL(k_gaussian_hit, grid_for(n, 256), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     n, rays, position, cov_inv6, hit_t);
+                     n, rays, position, rotation, scale, hit_t);
   return check_launch();
 }
 
 int rtgs_gaussian_eval(int32_t n, const float* pos, const float* dir, const float* position,
-                       const float* cov_inv6, const float* color_opacity, const float* sh, float* out,
-                       rtgs_stream_t stream) {
-  if (n <= 0 || !pos || !dir || !position || !cov_inv6 || !color_opacity || !out) return RTGS_EINVAL;
+                       const float* rotation, const float* scale, const float* color_opacity,
+                       const float* sh, float* out, rtgs_stream_t stream) {
+  if (n <= 0 || !pos || !dir || !position || !rotation || !scale || !color_opacity || !out) return RTGS_EINVAL;
   hipLaunchKernelGGL(k_gaussian_eval, grid_for(n, 256), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     n, pos, dir, position, cov_inv6, color_opacity, sh, out);
+                     n, pos, dir, position, rotation, scale, color_opacity, sh, out);
   return check_launch();
 }
 

@@ -106,7 +106,8 @@ struct TraceArgs {
 // ------------------------------------------------------------------------------------
 
 __global__ __launch_bounds__(256) void k_project(int32_t n, const float* __restrict__ pos,
-                                                  const float* __restrict__ ci6, FrameCam cam,
+                                                  const float* __restrict__ rot,
+                                                  const float* __restrict__ scale, FrameCam cam,
                                                   float4* __restrict__ bbox,
                                                   float4* __restrict__ slab_bbox,
                                                   float* __restrict__ rec) {
@@ -122,8 +123,10 @@ __global__ __launch_bounds__(256) void k_project(int32_t n, const float* __restr
   const double mx = cam.o[0] - (double)pos[3 * g + 0];
   const double my = cam.o[1] - (double)pos[3 * g + 1];
   const double mz = cam.o[2] - (double)pos[3 * g + 2];
-  const double Mxx = ci6[6 * g + 0], Mxy = ci6[6 * g + 1], Mxz = ci6[6 * g + 2];
-  const double Myy = ci6[6 * g + 3], Myz = ci6[6 * g + 4], Mzz = ci6[6 * g + 5];
+  // quaternion + scale -> inverse covariance, fp64 (utils/quaternion.py:99-121, gaussian.py:86-102)
+  double m6[6];
+  cov_inverse6(rot + 4 * (size_t)g, scale + 3 * (size_t)g, m6);
+  const double Mxx = m6[0], Mxy = m6[1], Mxz = m6[2], Myy = m6[3], Myz = m6[4], Mzz = m6[5];
   // u = M m ; C = m.M m - 3   (gaussian.py:217-219)
   const double u0 = Mxx * mx + Mxy * my + Mxz * mz;
   const double u1 = Mxy * mx + Myy * my + Myz * mz;
@@ -180,15 +183,38 @@ __global__ __launch_bounds__(256) void k_project(int32_t n, const float* __restr
                            (float)(X0 + hx + pad_x), (float)(Y0 + hy + pad_y));
       }
     }
+    // Expansion point.  For an ellipse: the point of the screen rectangle where delta is LARGEST
+    // (the Mahalanobis-nearest point to the conic centre: a convex 2-D QP, solved exactly by
+    // checking the centre and the minimiser of each edge).  Every on-screen pixel then has
+    // 0 <= terms <= delta(there) <= 3 A, so the fp32 Taylor evaluation never cancels, however
+    // far off-screen the centre is; and if even that maximum is <= 0 the Gaussian is invisible.
+    // Other conics (near the camera, well conditioned anyway) expand about the screen centre.
+    const double hw = 0.5 * cam.width, hh = 0.5 * cam.height;
+    double cx = 0.0, cy = 0.0;
+    if (keep && Q00 < 0.0 && det > 0.0) {
+      cx = X0; cy = Y0;
+      if (!(fabs(X0) <= hw && fabs(Y0) <= hh)) {
+        const double P00 = -Q00, P01 = -Q01, P11 = -Q11;
+        double best = inf;
+#pragma unroll
+        for (int edge = 0; edge < 4; ++edge) {
+          double px, py;
+          if (edge < 2) {   // x = -hw, +hw
+            px = edge == 0 ? -hw : hw;
+            py = fmin(fmax(Y0 - P01 * (px - X0) / P11, -hh), hh);
+          } else {          // y = -hh, +hh
+            py = edge == 2 ? -hh : hh;
+            px = fmin(fmax(X0 - P01 * (py - Y0) / P00, -hw), hw);
+          }
+          const double dx = px - X0, dy = py - Y0;
+          const double f = P00 * dx * dx + 2.0 * P01 * dx * dy + P11 * dy * dy;
+          if (f < best) { best = f; cx = px; cy = py; }
+        }
+        const double K = Q22 - (Q02 * X0 + Q12 * Y0);
+        if (!(best < K)) keep = false;   // delta/4 = K - f <= 0 on the whole screen (NaN: cull)
+      }
+    }
     if (keep && C < inf) {
-      // Expansion point: the conic centre snapped to the half-integer pixel-centre grid and
-      // clamped to the screen, so that (X - cx) is exact in fp32 and every on-screen pixel is
-      // evaluated close to it.  A quadratic's Taylor expansion is exact about any point.
-      const double hw = 0.5 * cam.width, hh = 0.5 * cam.height;
-      double cx = (X0 == X0 && fabs(X0) < inf) ? X0 : 0.0;
-      double cy = (Y0 == Y0 && fabs(Y0) < inf) ? Y0 : 0.0;
-      cx = fmin(fmax(cx, -hw), hw);
-      cy = fmin(fmax(cy, -hh), hh);
       cx = rint(2.0 * cx) * 0.5;
       cy = rint(2.0 * cy) * 0.5;
       // E_c = (cx, cy, -1)
@@ -334,6 +360,7 @@ __global__ __launch_bounds__(kTraceBlock, kHasSh ? RTGS_WAVES_PER_SIMD_SH : RTGS
   const int lane = tid & (kWave - 1);
   const int wave = tid >> 6;
   const int ltile = a.tile_order ? a.tile_order[blockIdx.x] : (int)blockIdx.x;
+  if ((unsigned)ltile >= gridDim.x) return;   // a malformed caller-supplied order must not write out of bounds
   const int tile = a.tile_first + ltile * a.tile_step;
   const int mi0 = (tile % a.tiles_x) * kTile;
   const int mj0 = (tile / a.tiles_x) * kTile;
@@ -711,7 +738,8 @@ int32_t rtgs_num_local_tiles(int32_t width, int32_t height, int32_t tile_first, 
 
 static int validate(const RtgsScene* scene, const RtgsCamera* cam, void* ws, size_t ws_bytes) {
   if (!scene || !cam || !ws) return RTGS_EINVAL;
-  if (scene->n <= 0 || !scene->position || !scene->cov_inv6 || !scene->color_opacity) return RTGS_EINVAL;
+  if (scene->n <= 0 || !scene->position || !scene->rotation || !scene->scale || !scene->color_opacity)
+    return RTGS_EINVAL;
   if (cam->width <= 0 || cam->height <= 0 || !(cam->fx > 0.f) || !(cam->fy > 0.f)) return RTGS_EINVAL;
   if (ws_bytes < rtgs_workspace_bytes(scene->n)) return RTGS_EWORKSPACE;
   if (reinterpret_cast<uintptr_t>(ws) & 15u) return RTGS_EINVAL;
@@ -728,8 +756,8 @@ int rtgs_project(const RtgsScene* scene, const RtgsCamera* cam, void* workspace,
   const FrameCam fc = make_frame_cam(*cam);
   const int block = 256;
   hipLaunchKernelGGL(k_project, dim3((scene->n + block - 1) / block), dim3(block), 0,
-                     static_cast<hipStream_t>(stream), scene->n, scene->position, scene->cov_inv6,
-                     fc, bbox, slab_bbox, rec);
+                     static_cast<hipStream_t>(stream), scene->n, scene->position, scene->rotation,
+                     scene->scale, fc, bbox, slab_bbox, rec);
   return check_launch();
 }
 

@@ -14,7 +14,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_size_t, c_u
 
 import torch  # noqa: F401  (must precede the CDLL load, see module docstring)
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_DEPTH = 16
 RAY_FLOATS = 8
 SH_COEFFS = 15
@@ -28,7 +28,7 @@ LIB_PATH = os.environ.get("RTGS_HIP_LIB") or os.path.join(
 
 
 class RtgsScene(Structure):
-    _fields_ = [("n", c_int32), ("position", c_void_p), ("cov_inv6", c_void_p),
+    _fields_ = [("n", c_int32), ("position", c_void_p), ("rotation", c_void_p), ("scale", c_void_p),
                 ("color_opacity", c_void_p), ("sh", c_void_p)]
 
 
@@ -60,9 +60,10 @@ PROTOTYPES = {
     "rtgs_untile": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "rtgs_closest_hit": (c_int32, [POINTER(RtgsScene), c_int32, c_void_p, c_void_p, c_void_p,
                                    c_void_p]),
-    "rtgs_gaussian_hit": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rtgs_gaussian_hit": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p]),
     "rtgs_gaussian_eval": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                     c_void_p, c_void_p, c_void_p]),
+                                     c_void_p, c_void_p, c_void_p, c_void_p]),
     "rtgs_quat_op": (c_int32, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rtgs_ray_get": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rtgs_disp_buffer": (c_int32, [c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p,

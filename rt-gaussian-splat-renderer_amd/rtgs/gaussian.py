@@ -77,25 +77,25 @@ class Gaussian:
     def hit(self, ray: Ray) -> vec2:
         """Ray/ellipsoid intersections (t1, t2), both inf on a miss (gaussian.py:203-230)."""
         dev = nat.device()
-        _, inv = self._cov_pair()
         rays = torch.from_numpy(ray.as_array()[None, :]).to(dev)
         pos = _t(self.position, (1, 3), dev)
+        rot, sc = _t(self.rotation, (1, 4), dev), _t(self.scale, (1, 3), dev)
         out = torch.empty((1, 2), dtype=torch.float32, device=dev)
-        nat.check(nat.lib().rtgs_gaussian_hit(1, nat.ptr(rays), nat.ptr(pos), nat.ptr(inv),
+        nat.check(nat.lib().rtgs_gaussian_hit(1, nat.ptr(rays), nat.ptr(pos), nat.ptr(rot), nat.ptr(sc),
                                               nat.ptr(out), nat.stream()), "rtgs_gaussian_hit")
         return vec2(out[0].cpu().numpy())
 
     def _eval(self, pos, direction, color, opacity, with_sh=True) -> np.ndarray:
         dev = nat.device()
-        _, inv = self._cov_pair()
+        rot, sc = _t(self.rotation, (1, 4), dev), _t(self.scale, (1, 3), dev)
         p = _t(pos, (1, 3), dev)
         d = _t(direction, (1, 3), dev)
         mu = _t(self.position, (1, 3), dev)
         colop = _t(list(color) + [opacity], (1, 4), dev)
         sh = _t(self.sh_array(), (1, 45), dev) if with_sh else None
         out = torch.empty((1, 4), dtype=torch.float32, device=dev)
-        nat.check(nat.lib().rtgs_gaussian_eval(1, nat.ptr(p), nat.ptr(d), nat.ptr(mu), nat.ptr(inv),
-                                               nat.ptr(colop), nat.ptr(sh), nat.ptr(out),
+        nat.check(nat.lib().rtgs_gaussian_eval(1, nat.ptr(p), nat.ptr(d), nat.ptr(mu), nat.ptr(rot),
+                                               nat.ptr(sc), nat.ptr(colop), nat.ptr(sh), nat.ptr(out),
                                                nat.stream()), "rtgs_gaussian_eval")
         return out[0].cpu().numpy()
 

@@ -2,7 +2,7 @@
 
 The reference's ``Scene`` owns an AoS Gaussian field plus a binned-SAH BVH that accelerates
 ``Scene.hit`` (scene.py:162-450).  Here the scene owns structure-of-arrays device buffers
-(position, inverse covariance, colour+opacity, optional SH) that the HIP kernels stream; the
+(position, rotation, scale, colour+opacity, optional SH) that the HIP kernels stream; the
 closest-hit *result* of ``Scene.hit`` (scene.py:433-437) is kept, the BVH is not built
 (SURVEY.md 8(f) #3): per-frame screen-space culling replaces it on the render path.
 """
@@ -109,7 +109,7 @@ class Scene:
         self.bvh_field = None
         self.gaussian_field = None  # scene.py:83 allocates a shape-() field; filled by load
         self.num_gaussians = 0
-        self.position = self.cov_inv6 = self.color_opacity = self.sh = None
+        self.position = self.rotation = self.scale = self.color_opacity = self.sh = None
         self.version = 0            # bumped by commit(): invalidates cached projections
         self.order = None           # stream slot -> index into gaussian_field
         self.sort_spatially = True  # Morton-order the streamed copies (see morton_order)
@@ -146,9 +146,9 @@ class Scene:
         self.commit(has_sh)
 
     def commit(self, has_sh: bool | None = None) -> None:
-        """(Re)build the device buffers the kernels stream from ``gaussian_field``:
-        quaternion+scale -> inverse covariance (gaussian.py:86-102 via ``rtgs_covariance``),
-        colour and opacity packed to 16 B.  The streamed copies are stored in Morton order
+        """(Re)build the device buffers the kernels stream from ``gaussian_field``: position,
+        quaternion, scale (the covariance of gaussian.py:86-102 is formed from these on the
+        device), colour and opacity packed to 16 B.  The streamed copies are stored in Morton order
         (``self.order`` maps a stream slot back to the ``gaussian_field`` index)."""
         f = self.gaussian_field
         n = f.n
@@ -163,13 +163,10 @@ class Scene:
             self.order = torch.arange(n, device=dev)
         o = self.order
         self.position = f.position[o].contiguous()
-        self.cov_inv6 = torch.empty((n, 6), dtype=torch.float32, device=dev)
-        # keep the permuted temporaries alive across the launch: a freed block would be handed
-        # straight to the next temporary by the caching allocator
-        rot_s, scale_s = f.rotation[o].contiguous(), f.scale[o].contiguous()
-        nat.check(nat.lib().rtgs_covariance(n, nat.ptr(rot_s), nat.ptr(scale_s), None,
-                                            nat.ptr(self.cov_inv6), nat.stream()), "rtgs_covariance")
-        del rot_s, scale_s
+        # quaternion + scale stay as they are: the kernels rebuild Sigma^-1 = R S^-2 R^T in fp64 per
+        # frame (an fp32-rounded inverse covariance flips grazing hits of needle-like Gaussians)
+        self.rotation = f.rotation[o].contiguous()
+        self.scale = f.scale[o].contiguous()
         self.color_opacity = torch.cat([f.color, f.opacity[:, None]], dim=1)[o].contiguous()
         if has_sh is None:
             has_sh = bool(torch.any(f.sh != 0).item())
@@ -210,7 +207,8 @@ class Scene:
         s = nat.RtgsScene()
         s.n = self.num_gaussians
         s.position = nat.ptr(self.position)
-        s.cov_inv6 = nat.ptr(self.cov_inv6)
+        s.rotation = nat.ptr(self.rotation)
+        s.scale = nat.ptr(self.scale)
         s.color_opacity = nat.ptr(self.color_opacity)
         s.sh = nat.ptr(self.sh)
         return s

@@ -191,9 +191,11 @@ def test_scene_load_file():
     assert f.n == 16
     for name in ("position", "rotation", "scale", "color", "opacity", "sh"):
         assert np_(getattr(f, name)) == pytest.approx(want[name], rel=2e-6, abs=1e-7), name
-    # inverse covariance of the loaded Gaussians vs the oracle (scales down to 4e-4 -> 6e6 entries)
+    # covariance kernel on the loaded Gaussians vs the oracle (scales down to 4e-4 -> 6e6 entries)
     minv = ref.gaussian_cov_inv(np_(f.rotation).astype(np.float64), np_(f.scale).astype(np.float64))
-    c = np_(scene.cov_inv6)
+    cinv = torch.empty((16, 6), dtype=torch.float32, device="cuda")
+    nat.check(nat.lib().rtgs_covariance(16, nat.ptr(f.rotation), nat.ptr(f.scale), None, nat.ptr(cinv), nat.stream()))
+    c = np_(cinv)
     got = np.stack([c[:, [0, 1, 2]], c[:, [1, 3, 4]], c[:, [2, 4, 5]]], axis=1)
     assert got == pytest.approx(minv, rel=5e-6)
     scene2 = rtgs.Scene()

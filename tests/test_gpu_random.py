@@ -118,3 +118,28 @@ def test_large_scene_instantiation(sh):
     worst = U.assert_parity(U.at(tracer.sample_buf, pix), want, f"large scene sh={sh}")
     assert want["hits"].mean() > 8
     print(f"large scene sh={sh}: max |err| {worst:.2e}")
+
+
+def test_needle_gaussians_keep_grazing_hits_consistent():
+    # regression for tools/fuzz_gpu.py seed 7004: a 70:1 needle whose silhouette grazes a pixel
+    # (|delta/4A| = 7e-5).  With an fp32-STORED inverse covariance the hit flipped (error 8.7e-3);
+    # the kernels now rebuild it in fp64 from quaternion + scale.
+    rng = np.random.default_rng(7004)
+    w, h = int(rng.integers(1, 300)), int(rng.integers(1, 200))
+    n = int(rng.choice([1, 2, 63, 64, 65, 300, 2000, 9000]))
+    sh = bool(rng.random() < 0.25)
+    arrays = synthetic.make_scene(n, max(w / h, 0.2), 7004, sh=sh)
+    arrays["scale"] = (arrays["scale"] * np.float32(rng.choice([0.3, 1.0, 3.0, 12.0]))).astype(np.float32)
+    if rng.random() < 0.3:
+        arrays["scale"][:, int(rng.integers(0, 3))] *= np.float32(rng.uniform(3, 20))
+    rot = scenes.quat_axis_angle(rng.normal(size=3), rng.uniform(0, 3.1))
+    pos = scenes.f32_tuple(rng.normal(size=3) * rng.choice([0.2, 1.0, 3.0, 8.0]))
+    f = float(np.float32(rng.uniform(0.3, 3.0) * max(h, 8)))
+    cam = dict(position=pos, rotation=rot, width=w, height=h, fx=f, fy=float(np.float32(f * rng.uniform(0.7, 1.4))))
+    depth = int(rng.integers(1, 17))
+    assert (n, w, h) == (9000, 39, 141) and arrays["scale"].max() / arrays["scale"].min() > 50
+    _, _, tracer = U.build(arrays, cam)
+    tracer.sample_all(depth)
+    torch.cuda.synchronize()
+    want = c_oracle.render(arrays, cam, depth)
+    U.assert_parity(tracer.sample_buf.cpu().numpy().reshape(-1, 3), want, "needle scene (fuzz seed 7004)")
