@@ -76,3 +76,26 @@ def crop_pixels(width, height, cw=64, ch=36, seed=7, extra=1024):
 def all_pixels(width, height):
     i, j = np.meshgrid(np.arange(width), np.arange(height), indexing="ij")
     return np.stack([i.ravel(), j.ravel()], axis=-1).astype(np.int32)
+
+
+def fuzz_case(seed):
+    """One seeded random (scene, camera, depth, shard count, mode) case of tools/fuzz_gpu.py: image
+    sizes 1..300 x 1..200, 1..9000 Gaussians (incl. slab-boundary counts), scale multipliers
+    0.3..12 with optional 3..20x needles, cameras from inside the cloud to 8 units away, any
+    orientation, fx != fy, depth 1..16.  mode 0 = the reference's one-peel-per-call pattern."""
+    rng = np.random.default_rng(seed)
+    w, h = int(rng.integers(1, 300)), int(rng.integers(1, 200))
+    n = int(rng.choice([1, 2, 63, 64, 65, 300, 2000, 9000]))
+    sh = bool(rng.random() < 0.25)
+    arrays = synthetic.make_scene(n, max(w / h, 0.2), seed, sh=sh)
+    arrays["scale"] = (arrays["scale"] * np.float32(rng.choice([0.3, 1.0, 3.0, 12.0]))).astype(np.float32)
+    if rng.random() < 0.3:
+        arrays["scale"][:, int(rng.integers(0, 3))] *= np.float32(rng.uniform(3, 20))
+    rot = quat_axis_angle(rng.normal(size=3), rng.uniform(0, 3.1))
+    pos = f32_tuple(rng.normal(size=3) * rng.choice([0.2, 1.0, 3.0, 8.0]))
+    f = float(np.float32(rng.uniform(0.3, 3.0) * max(h, 8)))
+    cam = dict(position=pos, rotation=rot, width=w, height=h, fx=f, fy=float(np.float32(f * rng.uniform(0.7, 1.4))))
+    depth = int(rng.integers(1, 17))
+    world = int(rng.choice([1, 1, 2, 5, 8]))
+    mode = int(rng.integers(0, 4))
+    return arrays, cam, depth, world, mode

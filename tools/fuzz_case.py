@@ -7,19 +7,7 @@ from rtgs import synthetic
 from oracle import c_oracle, rtgs_ref as ref
 
 def make(seed):
-    rng = np.random.default_rng(seed)
-    w, h = int(rng.integers(1, 300)), int(rng.integers(1, 200))
-    n = int(rng.choice([1, 2, 63, 64, 65, 300, 2000, 9000]))
-    sh = bool(rng.random() < 0.25)
-    arrays = synthetic.make_scene(n, max(w / h, 0.2), seed, sh=sh)
-    arrays["scale"] = (arrays["scale"] * np.float32(rng.choice([0.3, 1.0, 3.0, 12.0]))).astype(np.float32)
-    if rng.random() < 0.3:
-        arrays["scale"][:, int(rng.integers(0, 3))] *= np.float32(rng.uniform(3, 20))
-    rot = scenes.quat_axis_angle(rng.normal(size=3), rng.uniform(0, 3.1))
-    pos = scenes.f32_tuple(rng.normal(size=3) * rng.choice([0.2, 1.0, 3.0, 8.0]))
-    f = float(np.float32(rng.uniform(0.3, 3.0) * max(h, 8)))
-    cam = dict(position=pos, rotation=rot, width=w, height=h, fx=f, fy=float(np.float32(f * rng.uniform(0.7, 1.4))))
-    depth = int(rng.integers(1, 17))
+    arrays, cam, depth, _, _ = scenes.fuzz_case(seed)
     return arrays, cam, depth
 
 seed = int(sys.argv[1])

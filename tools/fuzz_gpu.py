@@ -11,27 +11,33 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 worst, bad, frag_tot, pix_tot = 0.0, [], 0, 0
 t0 = time.time()
 for seed in range(7000, 7000 + n_cases):
-    rng = np.random.default_rng(seed)
-    w, h = int(rng.integers(1, 300)), int(rng.integers(1, 200))
-    n = int(rng.choice([1, 2, 63, 64, 65, 300, 2000, 9000]))
-    sh = bool(rng.random() < 0.25)
-    arrays = synthetic.make_scene(n, max(w / h, 0.2), seed, sh=sh)
-    arrays["scale"] = (arrays["scale"] * np.float32(rng.choice([0.3, 1.0, 3.0, 12.0]))).astype(np.float32)
-    if rng.random() < 0.3:
-        arrays["scale"][:, int(rng.integers(0, 3))] *= np.float32(rng.uniform(3, 20))
-    rot = scenes.quat_axis_angle(rng.normal(size=3), rng.uniform(0, 3.1))
-    pos = scenes.f32_tuple(rng.normal(size=3) * rng.choice([0.2, 1.0, 3.0, 8.0]))
-    f = float(np.float32(rng.uniform(0.3, 3.0) * max(h, 8)))
-    cam = dict(position=pos, rotation=rot, width=w, height=h, fx=f, fy=float(np.float32(f * rng.uniform(0.7, 1.4))))
-    depth = int(rng.integers(1, 17))
+    arrays, cam, depth, world, mode = scenes.fuzz_case(seed)
+    w, h, n = cam["width"], cam["height"], arrays["position"].shape[0]
     scene = rtgs.Scene.from_arrays(**arrays)
     camera = rtgs.Camera(cam["position"], cam["rotation"], (w, h), (cam["fx"], cam["fy"]))
     tr = rtgs.RayTracer((w, h), scene, camera)
-    world = int(rng.choice([1, 1, 2, 5, 8]))
-    for r in range(world):
-        tr.trace(depth, tile_first=r, tile_step=world)
+    if mode == 0:      # the reference's call pattern: one peel per sample() call
+        for _ in range(depth):
+            tr.sample(depth)
+    else:
+        for r in range(world):
+            tr.trace(depth, tile_first=r, tile_step=world)
     torch.cuda.synchronize()
     got = tr.sample_buf.cpu().numpy().reshape(-1, 3)
+    if seed % 7 == 0:  # Scene.hit on the camera rays vs the first peel of the oracle
+        camera.generate_ray_field(camera.position, camera.rotation)
+        idx, t = scene.hit_batch(camera.cam_ray_field)
+        first = c_oracle.render(arrays, cam, 1)
+        hit_gpu = (idx.cpu().numpy().reshape(-1) >= 0)
+        hit_ref = first["hits"] > 0
+        ok = ~first["fragile"]
+        if (hit_gpu != hit_ref)[ok].any():
+            bad.append((seed, "scene.hit miss/hit mismatch", int((hit_gpu != hit_ref)[ok].sum())))
+        both = ok & hit_ref & hit_gpu
+        if both.any():
+            dt = np.abs(t.cpu().numpy().reshape(-1, 2)[both, 0] - first["start"][both])
+            if dt.max() > 1e-4 * max(1.0, first["start"][both].max()):   # fp32 ray directions vs fp64
+                bad.append((seed, "scene.hit t1 error", float(dt.max())))
     want = c_oracle.render(arrays, cam, depth, eps_q=1e-4 if arrays["scale"].max() > 1 else 1e-5)
     err = np.abs(got - want["sample"]).max(axis=1)
     solid = ~want["fragile"]
