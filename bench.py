@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--config", default="c3", help="c2 | c3 | c5 (SURVEY.md 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=256, help="rays of the NumPy baseline sample")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo "
+                    "only for functional rehearsal of the N > 1 path)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: all ranks on cuda:0")
     return ap.parse_args()
 
 
@@ -98,10 +101,15 @@ def main():
                              "(--nproc-per-node N)")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     import rtgs
     from rtgs import _native as nat
@@ -154,6 +162,15 @@ def main():
     torch.cuda.synchronize()
     project_ms = ev0.elapsed_time(ev1) / reps
 
+    verified = None
+    if world > 1 and rank == 0:
+        # the gathered, de-interleaved frame must equal a single-rank render of the same frame
+        single = TileParallelRenderer(scene, camera, depth=cfg.depth, rank=0, world=1)
+        single.render_frame()
+        single.finish()
+        torch.cuda.synchronize()
+        verified = bool(torch.equal(single.framebuffer, renderer.framebuffer))
+
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         mrays = cfg.rays / (elapsed / args.steps) / 1e6
@@ -181,6 +198,8 @@ def main():
                                  "k_trace time; screen-space culling skips most of that stream, "
                                  "so frac > 1 is possible; physical HBM bytes: profiles/"},
         }
+        if verified is not None:
+            line["verified"] = verified
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, arrays, cam, args.cpu_rays)
         print(json.dumps(line), flush=True)
