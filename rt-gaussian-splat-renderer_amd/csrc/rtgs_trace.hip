@@ -70,7 +70,8 @@ namespace {
 constexpr int kSlab = 64;                                 // Gaussians per slab = one wave
 // Batch sizes of the scan / expansion / colour-gather stages.  Measured optimum depends on the
 // number of slabs: c3 (1.6 k slabs) 2/2/4 -> 0.293 ms vs 0.344 with 4/4/8; c5 (15.6 k slabs, SH)
-// 4/4/8 -> 2.67 ms vs 3.11 with 2/2/4.  rtgs_trace picks the instantiation by scene size.
+// 4/4/8 -> 2.67 ms vs 3.11 with 2/2/4 (2.08 with the two-level scan below).  rtgs_trace picks
+// the instantiation by scene size.
 template <bool kBig>
 struct Tune {
   static constexpr int kSlabIters = kBig ? 4 : 2;           // slab bounds in flight per thread
@@ -82,7 +83,18 @@ struct Tune {
   static constexpr int kGroup = kBig ? 8 : 4;                // colour/opacity gathers in flight
   static_assert(kSlabCap >= kSlabStep + 64, "slab list too small");
 };
-constexpr int kBigSceneSlabs = 4096;   // scenes with more slabs than this use Tune<true>
+#ifndef RTGS_BIG_SLABS
+#define RTGS_BIG_SLABS 4096
+#endif
+constexpr int kBigSceneSlabs = RTGS_BIG_SLABS;   // scenes with more slabs than this use Tune<true>
+#ifndef RTGS_SUPER
+#define RTGS_SUPER 16
+#endif
+// Tune<true> scans slab bounds in two levels: bounds of kSuper consecutive slabs first, then the
+// slabs of the surviving groups only.  c5 (15.6 k slabs): the flat scan was 27 % of a workgroup's
+// lifetime (every one of 32 400 workgroups streaming 250 KB of bounds through L2); c3 (1.6 k slabs)
+// is faster flat (one barrier less), so Tune<false> keeps the flat scan.
+constexpr int kSuper = RTGS_SUPER;
 
 struct TraceArgs {
   int32_t n;
@@ -255,6 +267,24 @@ __global__ __launch_bounds__(256) void k_project(int32_t n, const float* __restr
   if ((threadIdx.x & (kWave - 1)) == 0 && live) slab_bbox[g0 / kSlab] = bb;
 }
 
+// Union bounds of kSuper consecutive slabs (big scenes only; see kSuper).
+__global__ __launch_bounds__(256) void k_super_bbox(int32_t nslabs, const float4* __restrict__ slab_bbox,
+                                                     float4* __restrict__ super_bbox) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u * kSuper >= nslabs) return;
+  float4 bb = make_float4(kInf, kInf, -kInf, -kInf);
+#pragma unroll
+  for (int k = 0; k < kSuper; ++k) {
+    const int sl = u * kSuper + k;
+    if (sl < nslabs) {
+      const float4 b = slab_bbox[sl];
+      bb.x = fminf(bb.x, b.x); bb.y = fminf(bb.y, b.y);
+      bb.z = fmaxf(bb.z, b.z); bb.w = fmaxf(bb.w, b.w);
+    }
+  }
+  super_bbox[u] = bb;
+}
+
 // ------------------------------------------------------------------------------------
 // trace
 // ------------------------------------------------------------------------------------
@@ -344,6 +374,7 @@ template <bool kHasSh, bool kBig, int kK>
 __global__ __launch_bounds__(kTraceBlock, kHasSh ? RTGS_WAVES_PER_SIMD_SH : RTGS_WAVES_PER_SIMD) void k_trace(const TraceArgs a,
                                                           const float4* __restrict__ bbox,
                                                           const float4* __restrict__ slab_bbox,
+                                                          const float4* __restrict__ super_bbox,
                                                           const float4* __restrict__ rec,
                                                           const float4* __restrict__ colop,
                                                           const float* __restrict__ sh) {
@@ -355,6 +386,9 @@ __global__ __launch_bounds__(kTraceBlock, kHasSh ? RTGS_WAVES_PER_SIMD_SH : RTGS
   __shared__ int s_idx[kListCap];
   __shared__ int s_wcnt[2][kWavesPerTile];
   __shared__ int s_cnt[kBatch];
+  constexpr int kSuperStep = kSlabIters * kTraceBlock;   // slab groups scanned per outer step
+  __shared__ int s_super[kBig ? kSuperStep : 1];
+  __shared__ int s_wcnt2[2][kWavesPerTile];
 
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
@@ -411,14 +445,57 @@ __global__ __launch_bounds__(kTraceBlock, kHasSh ? RTGS_WAVES_PER_SIMD_SH : RTGS
   st[0] = __builtin_amdgcn_s_memtime();
 #endif
   int scnt = 0;  // surviving slabs listed so far: identical in every thread
-  for (int sbase = 0, par = 0; sbase < nslabs; sbase += kSlabStep, par ^= 1) {
+  const int nsuper = kBig ? (nslabs + kSuper - 1) / kSuper : 1;
+  int par = 0;
+  for (int ub = 0, upar = 0; ub < nsuper; ub += kSuperStep, upar ^= 1) {
+  int nitems = nslabs;
+  if constexpr (kBig) {
+    // ---- level 1: bounds of kSuper-slab groups; survivors in stream order into s_super ----
+    float4 gbb[kSlabIters];
+#pragma unroll
+    for (int it = 0; it < kSlabIters; ++it) {
+      const int u = ub + it * kTraceBlock + tid;
+      gbb[it] = make_float4(kInf, kInf, -kInf, -kInf);
+      if (u < nsuper) gbb[it] = super_bbox[u];
+    }
+    unsigned long long um[kSlabIters];
+    int ucnt = 0;
+#pragma unroll
+    for (int it = 0; it < kSlabIters; ++it) {
+      const bool keep = gbb[it].x <= mXhi && gbb[it].z >= mXlo && gbb[it].y <= mYhi && gbb[it].w >= mYlo;
+      um[it] = __ballot(keep);
+      ucnt += __popcll(um[it]);
+    }
+    if (lane == 0) s_wcnt2[upar][wave] = ucnt;
+    __syncthreads();
+    int uoff = 0, utot = 0;
+#pragma unroll
+    for (int w = 0; w < kWavesPerTile; ++w) {
+      const int c = s_wcnt2[upar][w];
+      uoff += (w < wave) ? c : 0;
+      utot += c;
+    }
+#pragma unroll
+    for (int it = 0; it < kSlabIters; ++it) {
+      if ((um[it] >> lane) & 1ull) s_super[uoff + __popcll(um[it] & lane_lt)] = ub + it * kTraceBlock + tid;
+      uoff += __popcll(um[it]);
+    }
+    __syncthreads();
+    nitems = utot * kSuper;
+  }
+  const bool last_outer = ub + kSuperStep >= nsuper;
+  for (int sbase = 0; sbase < nitems || (last_outer && sbase == 0); sbase += kSlabStep, par ^= 1) {
     // ---- scan slab bounds; keep the slabs that touch the macro-tile.  The list is built
     // without atomics: every wave publishes its count, one barrier later every thread derives
     // the same offsets (s_wcnt is double-buffered by step parity).
     float4 sb[kSlabIters];
+    int slid[kSlabIters];
 #pragma unroll
     for (int it = 0; it < kSlabIters; ++it) {
-      const int sl = sbase + it * kTraceBlock + tid;
+      const int item = sbase + it * kTraceBlock + tid;
+      int sl = item;
+      if constexpr (kBig) sl = item < nitems ? s_super[item / kSuper] * kSuper + (item % kSuper) : nslabs;
+      slid[it] = sl;
       sb[it] = make_float4(kInf, kInf, -kInf, -kInf);
       if (sl < nslabs) sb[it] = slab_bbox[sl];
     }
@@ -442,10 +519,10 @@ __global__ __launch_bounds__(kTraceBlock, kHasSh ? RTGS_WAVES_PER_SIMD_SH : RTGS
 #pragma unroll
     for (int it = 0; it < kSlabIters; ++it) {
       if ((keep_m[it] >> lane) & 1ull)
-        s_slab[off + __popcll(keep_m[it] & lane_lt)] = sbase + it * kTraceBlock + tid;
+        s_slab[off + __popcll(keep_m[it] & lane_lt)] = slid[it];
       off += __popcll(keep_m[it]);
     }
-    const bool last = sbase + kSlabStep >= nslabs;
+    const bool last = last_outer && sbase + kSlabStep >= nitems;
     if (scnt + kSlabStep <= kSlabCap && !last) continue;
     __syncthreads();  // the slab list is complete
 #if RTGS_STAMPS
@@ -589,6 +666,7 @@ __global__ __launch_bounds__(kTraceBlock, kHasSh ? RTGS_WAVES_PER_SIMD_SH : RTGS
     }
     scnt = 0;
   }
+  }
 
 #if RTGS_STAMPS
   st[3] = __builtin_amdgcn_s_memtime();
@@ -640,7 +718,7 @@ __global__ __launch_bounds__(kTraceBlock, kHasSh ? RTGS_WAVES_PER_SIMD_SH : RTGS
         prev_tbits = tbits;
         float4 co = cog[j];
         if (kHasSh) {
-          if (valid) {
+          if (valid) {   // (gathering for every slot, valid or not, to batch the loads: 2.24 vs 2.08 ms on c5)
             const float* sp = sh + (size_t)gi * (RTGS_SH_COEFFS * 3);
 #pragma unroll
             for (int q = 0; q < RTGS_SH_COEFFS; ++q) {
@@ -720,7 +798,8 @@ extern "C" {
 size_t rtgs_workspace_bytes(int32_t n) {
   if (n <= 0) return 0;
   const size_t nn = ((size_t)n + 63) & ~(size_t)63;
-  return nn * sizeof(float4) + nn * kRecFloats * sizeof(float) + (nn / kSlab) * sizeof(float4);
+  const size_t nslabs = nn / kSlab, nsuper = (nslabs + kSuper - 1) / kSuper;
+  return nn * sizeof(float4) + nn * kRecFloats * sizeof(float) + (nslabs + nsuper) * sizeof(float4);
 }
 
 int32_t rtgs_tile_size(void) { return kTile; }
@@ -758,6 +837,12 @@ int rtgs_project(const RtgsScene* scene, const RtgsCamera* cam, void* workspace,
   hipLaunchKernelGGL(k_project, dim3((scene->n + block - 1) / block), dim3(block), 0,
                      static_cast<hipStream_t>(stream), scene->n, scene->position, scene->rotation,
                      scene->scale, fc, bbox, slab_bbox, rec);
+  const int nslabs = (int)(nn / kSlab);
+  if (nslabs > kBigSceneSlabs) {
+    const int nsuper = (nslabs + kSuper - 1) / kSuper;
+    hipLaunchKernelGGL(k_super_bbox, dim3((nsuper + block - 1) / block), dim3(block), 0,
+                       static_cast<hipStream_t>(stream), nslabs, slab_bbox, slab_bbox + nslabs);
+  }
   return check_launch();
 }
 
@@ -794,6 +879,7 @@ int rtgs_trace(const RtgsScene* scene, const RtgsCamera* cam, const RtgsTracePar
   const float4* bbox = static_cast<const float4*>(workspace);
   const float4* rec = bbox + nn;
   const float4* slab_bbox = rec + nn * (kRecFloats / 4);
+  const float4* super_bbox = slab_bbox + nn / kSlab;
   const float4* colop = reinterpret_cast<const float4*>(scene->color_opacity);
   a.sample = sample_buf;
   a.att = attenuation_buf;
@@ -805,7 +891,7 @@ int rtgs_trace(const RtgsScene* scene, const RtgsCamera* cam, const RtgsTracePar
   const float* sh = scene->sh;
 #define RTGS_LAUNCH(HAS_SH, BIG, K)                                                                \
   hipLaunchKernelGGL((k_trace<HAS_SH, BIG, K>), dim3(local), dim3(kTraceBlock), 0, s, a, bbox,        \
-                     slab_bbox, rec, colop, sh)
+                     slab_bbox, super_bbox, rec, colop, sh)
 #define RTGS_LAUNCH_K(HAS_SH, BIG) \
   do { if (params->depth == 1) RTGS_LAUNCH(HAS_SH, BIG, 1); else RTGS_LAUNCH(HAS_SH, BIG, RTGS_MAX_DEPTH); } while (0)
   if (sh) { if (big) RTGS_LAUNCH_K(true, true); else RTGS_LAUNCH_K(true, false); }

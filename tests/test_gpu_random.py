@@ -120,6 +120,23 @@ def test_large_scene_instantiation(sh):
     print(f"large scene sh={sh}: max |err| {worst:.2e}")
 
 
+def test_very_large_scene_two_outer_scan_steps():
+    # Tune<true> scans bounds of 16-slab groups first, 1024 groups per step: more than
+    # 1024 * 16 * 64 = 1 048 576 Gaussians takes a second outer step of that two-level scan
+    n, w, h = 1_100_000, 160, 90
+    arrays = synthetic.make_scene(n, w / h, 5151)
+    cam = synthetic.bench_camera(w, h)
+    _, _, tracer = U.build(arrays, cam)
+    tracer.sample_all(16)
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(2)
+    pix = np.stack([rng.integers(0, w, 500), rng.integers(0, h, 500)], axis=-1).astype(np.int32)
+    want = c_oracle.render(arrays, cam, 16, pix)
+    worst = U.assert_parity(U.at(tracer.sample_buf, pix), want, "very large scene")
+    assert want["hits"].mean() > 8
+    print(f"very large scene: max |err| {worst:.2e}")
+
+
 def test_needle_gaussians_keep_grazing_hits_consistent():
     # regression for tools/fuzz_gpu.py seed 7004: a 70:1 needle whose silhouette grazes a pixel
     # (|delta/4A| = 7e-5).  With an fp32-STORED inverse covariance the hit flipped (error 8.7e-3);

@@ -6,7 +6,7 @@ import numpy as np, torch
 import rtgs
 from rtgs import synthetic, _native as nat
 from rtgs.parallel import HipBackend
-cfg = synthetic.CONFIGS["c3"]
+cfg = synthetic.CONFIGS[os.environ.get("RTGS_CFG", "c3")]
 arrays = synthetic.make_config_scene(cfg); cam = synthetic.bench_camera(cfg.width, cfg.height)
 scene = rtgs.Scene.from_arrays(**arrays)
 camera = rtgs.Camera(cam["position"], cam["rotation"], (cfg.width, cfg.height), (cam["fx"], cam["fy"]))
@@ -17,7 +17,7 @@ for world in (1, 8):
     per = (total + world - 1) // world
     compact = b.alloc(per, T, T, 3)
     stamps = torch.zeros((per, 8), dtype=torch.int64, device="cuda")
-    params = nat.RtgsTraceParams(16, 0.0, 0, world, nat.TRACE_COMPACT)
+    params = nat.RtgsTraceParams(cfg.depth, 0.0, 0, world, nat.TRACE_COMPACT)
     for _ in range(3):
         nat.check(nat.lib().rtgs_trace(scene.native(), camera.native(), params, nat.ptr(compact), stamps.data_ptr(),
                                        None, 1, nat.ptr(b.workspace), b.workspace.numel(), 1, nat.stream()))
