@@ -79,6 +79,10 @@ typedef struct RtgsCamera {
                                      shard's pixels are overwritten                          */
 #define RTGS_TRACE_COMPACT 4u     /* sample_buf is the shard-compact [local_tile][T][T][3], T = rtgs_tile_size(),
                                      buffer that rtgs_untile scatters, not the (W,H,3) image  */
+/* scheduling only, same pixels: force / forbid the two-waves-per-8x8-tile form of the kernel
+ * that launches of few tiles (small shards) get by default */
+#define RTGS_TRACE_SPLIT_ON 8u
+#define RTGS_TRACE_SPLIT_OFF 16u
 
 typedef struct RtgsTraceParams {
   int32_t depth;        /* peels performed by this call, 1..RTGS_MAX_DEPTH               */

@@ -72,13 +72,15 @@ constexpr int kSlab = 64;                                 // Gaussians per slab 
 // number of slabs: c3 (1.6 k slabs) 2/2/4 -> 0.293 ms vs 0.344 with 4/4/8; c5 (15.6 k slabs, SH)
 // 4/4/8 -> 2.67 ms vs 3.11 with 2/2/4 (2.08 with the two-level scan below).  rtgs_trace picks
 // the instantiation by scene size.
-template <bool kBig>
+template <bool kBig, int kSplit = 1>
 struct Tune {
-  static constexpr int kSlabIters = kBig ? 4 : 2;           // slab bounds in flight per thread
-  static constexpr int kSlabStep = kSlabIters * kTraceBlock;  // slabs scanned per barrier
+  static constexpr int kWaves = kWavesPerTile * kSplit;     // waves per workgroup
+  static constexpr int kBlock = kWaves * kWave;             // threads per workgroup
+  static constexpr int kSlabIters = (kBig ? 4 : 2) / kSplit;  // slab bounds in flight per thread
+  static constexpr int kSlabStep = kSlabIters * kBlock;     // slabs scanned per barrier
   static constexpr int kSlabCap = 2048;                      // LDS list of surviving slabs
   static constexpr int kSlabsPerWave = kBig ? 4 : 2;         // slabs one wave expands per batch
-  static constexpr int kBatch = kSlabsPerWave * kWavesPerTile;  // slabs expanded per batch
+  static constexpr int kBatch = kSlabsPerWave * kWaves;      // slabs expanded per batch
   static constexpr int kListCap = kBatch * kSlab;            // LDS list of surviving Gaussians
   static constexpr int kGroup = kBig ? 8 : 4;                // colour/opacity gathers in flight
   static_assert(kSlabCap >= kSlabStep + 64, "slab list too small");
@@ -87,6 +89,10 @@ struct Tune {
 #define RTGS_BIG_SLABS 4096
 #endif
 constexpr int kBigSceneSlabs = RTGS_BIG_SLABS;   // scenes with more slabs than this use Tune<true>
+#ifndef RTGS_SPLIT_MAX_TILES
+#define RTGS_SPLIT_MAX_TILES 1024
+#endif
+constexpr int kSplitMaxTiles = RTGS_SPLIT_MAX_TILES;
 #ifndef RTGS_SUPER
 #define RTGS_SUPER 16
 #endif
@@ -370,25 +376,39 @@ __device__ __forceinline__ void sh_basis(float x, float y, float z, float (&Y)[R
 
 // kK = list length: RTGS_MAX_DEPTH, or 1 for single-peel calls (the reference viewer's one
 // sample_step per frame), where the list degenerates to "the nearest hit so far".
-template <bool kHasSh, bool kBig, int kK>
-__global__ __launch_bounds__(kTraceBlock, kHasSh ? RTGS_WAVES_PER_SIMD_SH : RTGS_WAVES_PER_SIMD) void k_trace(const TraceArgs a,
+//
+// kSplit = 2 (shards that are a single resident round, see rtgs_trace): TWO waves per 8x8 tile.
+// Both walk the same survivor stream and take alternate candidates, so the critical path of a
+// heavy tile halves; at the end the second wave hands its list over through LDS and the first
+// merges (bitonic, ordered by (t1, index) = arrival order) and composites.  Same pixels bit for
+// bit as kSplit = 1.
+template <bool kHasSh, bool kBig, int kK, int kSplit>
+__global__ __launch_bounds__(kTraceBlock * kSplit, kHasSh ? RTGS_WAVES_PER_SIMD_SH : RTGS_WAVES_PER_SIMD) void k_trace(const TraceArgs a,
                                                           const float4* __restrict__ bbox,
                                                           const float4* __restrict__ slab_bbox,
                                                           const float4* __restrict__ super_bbox,
                                                           const float4* __restrict__ rec,
                                                           const float4* __restrict__ colop,
                                                           const float* __restrict__ sh) {
-  using TN = Tune<kBig>;
+  static_assert(kSplit == 1 || kSplit == 2, "one or two waves per 8x8 tile");
+  using TN = Tune<kBig, kSplit>;
   constexpr int kSlabIters = TN::kSlabIters, kSlabStep = TN::kSlabStep, kSlabCap = TN::kSlabCap,
-                kSlabsPerWave = TN::kSlabsPerWave, kBatch = TN::kBatch, kListCap = TN::kListCap;
+                kSlabsPerWave = TN::kSlabsPerWave, kBatch = TN::kBatch, kListCap = TN::kListCap,
+                kWaves = TN::kWaves, kBlock = TN::kBlock;
+  // the survivor list and (kSplit == 2) the list hand-over share one LDS pool: the hand-over
+  // happens after the last barrier of the candidate loop
+  constexpr int kMergeWords = kSplit == 2 ? kWavesPerTile * 3 * kK * kWave : 0;
+  constexpr int kListF4 = kListCap + kListCap / 4;          // float4 bounds + int indices
+  constexpr int kPoolF4 = kListF4 > kMergeWords / 4 ? kListF4 : kMergeWords / 4;
+  __shared__ float4 s_pool[kPoolF4];
+  float4* const s_bb = s_pool;
+  int* const s_idx = reinterpret_cast<int*>(s_pool + kListCap);
   __shared__ int s_slab[kSlabCap];
-  __shared__ float4 s_bb[kListCap];
-  __shared__ int s_idx[kListCap];
-  __shared__ int s_wcnt[2][kWavesPerTile];
+  __shared__ int s_wcnt[2][kWaves];
   __shared__ int s_cnt[kBatch];
-  constexpr int kSuperStep = kSlabIters * kTraceBlock;   // slab groups scanned per outer step
+  constexpr int kSuperStep = kSlabIters * kBlock;   // slab groups scanned per outer step
   __shared__ int s_super[kBig ? kSuperStep : 1];
-  __shared__ int s_wcnt2[2][kWavesPerTile];
+  __shared__ int s_wcnt2[2][kWaves];
 
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
@@ -398,8 +418,10 @@ __global__ __launch_bounds__(kTraceBlock, kHasSh ? RTGS_WAVES_PER_SIMD_SH : RTGS
   const int tile = a.tile_first + ltile * a.tile_step;
   const int mi0 = (tile % a.tiles_x) * kTile;
   const int mj0 = (tile / a.tiles_x) * kTile;
-  const int wi0 = mi0 + (wave % kWavesX) * kWaveTile;
-  const int wj0 = mj0 + (wave / kWavesX) * kWaveTile;
+  const int sub = wave % kWavesPerTile;    // which 8x8 tile of the macro-tile
+  const int role = __builtin_amdgcn_readfirstlane(wave / kWavesPerTile);   // kSplit == 2: 0 keeps the list, 1 helps
+  const int wi0 = mi0 + (sub % kWavesX) * kWaveTile;
+  const int wj0 = mj0 + (sub / kWavesX) * kWaveTile;
   const int pi = wi0 + (lane >> 3);
   const int pj = wj0 + (lane & 7);
   const bool in_img = pi < a.width && pj < a.height;
@@ -445,6 +467,7 @@ __global__ __launch_bounds__(kTraceBlock, kHasSh ? RTGS_WAVES_PER_SIMD_SH : RTGS
   st[0] = __builtin_amdgcn_s_memtime();
 #endif
   int scnt = 0;  // surviving slabs listed so far: identical in every thread
+  int turn = 0;  // kSplit == 2: candidates of this 8x8 tile seen so far (wave-uniform)
   const int nsuper = kBig ? (nslabs + kSuper - 1) / kSuper : 1;
   int par = 0;
   for (int ub = 0, upar = 0; ub < nsuper; ub += kSuperStep, upar ^= 1) {
@@ -454,7 +477,7 @@ __global__ __launch_bounds__(kTraceBlock, kHasSh ? RTGS_WAVES_PER_SIMD_SH : RTGS
     float4 gbb[kSlabIters];
 #pragma unroll
     for (int it = 0; it < kSlabIters; ++it) {
-      const int u = ub + it * kTraceBlock + tid;
+      const int u = ub + it * kBlock + tid;
       gbb[it] = make_float4(kInf, kInf, -kInf, -kInf);
       if (u < nsuper) gbb[it] = super_bbox[u];
     }
@@ -470,14 +493,14 @@ __global__ __launch_bounds__(kTraceBlock, kHasSh ? RTGS_WAVES_PER_SIMD_SH : RTGS
     __syncthreads();
     int uoff = 0, utot = 0;
 #pragma unroll
-    for (int w = 0; w < kWavesPerTile; ++w) {
+    for (int w = 0; w < kWaves; ++w) {
       const int c = s_wcnt2[upar][w];
       uoff += (w < wave) ? c : 0;
       utot += c;
     }
 #pragma unroll
     for (int it = 0; it < kSlabIters; ++it) {
-      if ((um[it] >> lane) & 1ull) s_super[uoff + __popcll(um[it] & lane_lt)] = ub + it * kTraceBlock + tid;
+      if ((um[it] >> lane) & 1ull) s_super[uoff + __popcll(um[it] & lane_lt)] = ub + it * kBlock + tid;
       uoff += __popcll(um[it]);
     }
     __syncthreads();
@@ -492,7 +515,7 @@ __global__ __launch_bounds__(kTraceBlock, kHasSh ? RTGS_WAVES_PER_SIMD_SH : RTGS
     int slid[kSlabIters];
 #pragma unroll
     for (int it = 0; it < kSlabIters; ++it) {
-      const int item = sbase + it * kTraceBlock + tid;
+      const int item = sbase + it * kBlock + tid;
       int sl = item;
       if constexpr (kBig) sl = item < nitems ? s_super[item / kSuper] * kSuper + (item % kSuper) : nslabs;
       slid[it] = sl;
@@ -511,7 +534,7 @@ __global__ __launch_bounds__(kTraceBlock, kHasSh ? RTGS_WAVES_PER_SIMD_SH : RTGS
     __syncthreads();
     int off = scnt;
 #pragma unroll
-    for (int w = 0; w < kWavesPerTile; ++w) {
+    for (int w = 0; w < kWaves; ++w) {
       const int c = s_wcnt[par][w];
       off += (w < wave) ? c : 0;
       scnt += c;
@@ -541,7 +564,7 @@ __global__ __launch_bounds__(kTraceBlock, kHasSh ? RTGS_WAVES_PER_SIMD_SH : RTGS
       unsigned long long gm[kSlabsPerWave];
 #pragma unroll
       for (int q = 0; q < kSlabsPerWave; ++q) {
-        const int k = b0 + q * kWavesPerTile + wave;
+        const int k = b0 + q * kWaves + wave;
         gb[q] = make_float4(kInf, kInf, -kInf, -kInf);
         if (k < bend) {
           const int g = s_slab[k] * kSlab + lane;
@@ -552,7 +575,7 @@ __global__ __launch_bounds__(kTraceBlock, kHasSh ? RTGS_WAVES_PER_SIMD_SH : RTGS
       for (int q = 0; q < kSlabsPerWave; ++q) {
         const bool keep = gb[q].x <= mXhi && gb[q].z >= mXlo && gb[q].y <= mYhi && gb[q].w >= mYlo;
         gm[q] = __ballot(keep);
-        if (lane == 0) s_cnt[q * kWavesPerTile + wave] = __popcll(gm[q]);
+        if (lane == 0) s_cnt[q * kWaves + wave] = __popcll(gm[q]);
       }
       __syncthreads();
       int cnt = 0;
@@ -560,15 +583,15 @@ __global__ __launch_bounds__(kTraceBlock, kHasSh ? RTGS_WAVES_PER_SIMD_SH : RTGS
 #pragma unroll
       for (int q = 0; q < kSlabsPerWave; ++q) {
 #pragma unroll
-        for (int w = 0; w < kWavesPerTile; ++w) {
+        for (int w = 0; w < kWaves; ++w) {
           if (w == wave) goff[q] = cnt;
-          cnt += s_cnt[q * kWavesPerTile + w];
+          cnt += s_cnt[q * kWaves + w];
         }
       }
 #pragma unroll
       for (int q = 0; q < kSlabsPerWave; ++q) {
         if ((gm[q] >> lane) & 1ull) {
-          const int k = b0 + q * kWavesPerTile + wave;
+          const int k = b0 + q * kWaves + wave;
           const int slot = goff[q] + __popcll(gm[q] & lane_lt);
           s_idx[slot] = s_slab[k] * kSlab + lane;
           s_bb[slot] = gb[q];
@@ -588,6 +611,16 @@ __global__ __launch_bounds__(kTraceBlock, kHasSh ? RTGS_WAVES_PER_SIMD_SH : RTGS
           if (slot < cnt) { g = s_idx[slot]; wb = s_bb[slot]; }
           const bool pass = wb.x <= wXhi && wb.z >= wXlo && wb.y <= wYhi && wb.w >= wYlo;
           unsigned long long m = __ballot(pass);
+          if constexpr (kSplit == 2) {
+            // keep every other candidate: prefix parity of the mask marks the 1st, 3rd, ... set
+            // bit; `turn` carries the parity over from the previous chunks
+            unsigned long long par_m = m ^ (m << 1);
+            par_m ^= par_m << 2; par_m ^= par_m << 4; par_m ^= par_m << 8;
+            par_m ^= par_m << 16; par_m ^= par_m << 32;
+            const bool odd_first = ((turn ^ role) & 1) == 0;   // this wave takes the 1st, 3rd, ...
+            turn += __popcll(m);
+            m &= odd_first ? par_m : ~par_m;
+          }
 #if RTGS_ABLATE >= 3
           asm volatile("" ::"s"(m));
           m = 0;
@@ -666,6 +699,47 @@ __global__ __launch_bounds__(kTraceBlock, kHasSh ? RTGS_WAVES_PER_SIMD_SH : RTGS
     }
     scnt = 0;
   }
+  }
+
+  if constexpr (kSplit == 2) {
+    // ---- hand the helper wave's list over and merge: min(A[i], B[K-1-i]) is the bitonic
+    // sequence of the K smallest of both; log2(K) half-cleaners sort it.  Order = (t1, index).
+    unsigned* const mp = reinterpret_cast<unsigned*>(s_pool) + sub * (3 * kK * kWave) + lane;
+    if (role == 1) {
+#pragma unroll
+      for (int k = 0; k < kK; ++k) {
+        mp[(0 * kK + k) * kWave] = key[k];
+        mp[(1 * kK + k) * kWave] = kidx[k];
+        mp[(2 * kK + k) * kWave] = __float_as_uint(wexp[k]);
+      }
+    }
+    __syncthreads();
+    if (role == 1) return;
+#pragma unroll
+    for (int i = 0; i < kK; ++i) {
+      const int j = kK - 1 - i;
+      const unsigned tb = mp[(0 * kK + j) * kWave], ib = mp[(1 * kK + j) * kWave];
+      const float wb2 = __uint_as_float(mp[(2 * kK + j) * kWave]);
+      const bool lt = tb < key[i] || (tb == key[i] && ib < kidx[i]);
+      key[i] = lt ? tb : key[i];
+      kidx[i] = lt ? ib : kidx[i];
+      wexp[i] = lt ? wb2 : wexp[i];
+    }
+#pragma unroll
+    for (int d = kK / 2; d > 0; d >>= 1) {
+#pragma unroll
+      for (int i = 0; i < kK; ++i) {
+        if ((i & d) == 0) {
+          const int j = i + d;
+          const bool sw = key[j] < key[i] || (key[j] == key[i] && kidx[j] < kidx[i]);
+          const unsigned t0 = key[i], i0 = kidx[i];
+          const float w0 = wexp[i];
+          key[i] = sw ? key[j] : t0;   key[j] = sw ? t0 : key[j];
+          kidx[i] = sw ? kidx[j] : i0; kidx[j] = sw ? i0 : kidx[j];
+          wexp[i] = sw ? wexp[j] : w0; wexp[j] = sw ? w0 : wexp[j];
+        }
+      }
+    }
   }
 
 #if RTGS_STAMPS
@@ -889,11 +963,22 @@ int rtgs_trace(const RtgsScene* scene, const RtgsCamera* cam, const RtgsTracePar
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool big = (scene->n + kSlab - 1) / kSlab > kBigSceneSlabs;
   const float* sh = scene->sh;
-#define RTGS_LAUNCH(HAS_SH, BIG, K)                                                                \
-  hipLaunchKernelGGL((k_trace<HAS_SH, BIG, K>), dim3(local), dim3(kTraceBlock), 0, s, a, bbox,        \
-                     slab_bbox, super_bbox, rec, colop, sh)
-#define RTGS_LAUNCH_K(HAS_SH, BIG) \
-  do { if (params->depth == 1) RTGS_LAUNCH(HAS_SH, BIG, 1); else RTGS_LAUNCH(HAS_SH, BIG, RTGS_MAX_DEPTH); } while (0)
+  // Two waves per 8x8 tile when the launch is at most kSplitMaxTiles workgroups (a shard that is
+  // about one resident round: its time is the critical path of its heaviest tile, and halving
+  // that is worth the extra merge); callers can force either form.
+  bool split = local <= kSplitMaxTiles;
+  if (params->flags & RTGS_TRACE_SPLIT_ON) split = true;
+  if (params->flags & RTGS_TRACE_SPLIT_OFF) split = false;
+  if (params->depth == 1) split = false;
+#define RTGS_LAUNCH(HAS_SH, BIG, K, SPLIT)                                                         \
+  hipLaunchKernelGGL((k_trace<HAS_SH, BIG, K, SPLIT>), dim3(local), dim3(kTraceBlock * SPLIT), 0, s, a, \
+                     bbox, slab_bbox, super_bbox, rec, colop, sh)
+#define RTGS_LAUNCH_K(HAS_SH, BIG)                                                  \
+  do {                                                                              \
+    if (params->depth == 1) RTGS_LAUNCH(HAS_SH, BIG, 1, 1);                         \
+    else if (split) RTGS_LAUNCH(HAS_SH, BIG, RTGS_MAX_DEPTH, 2);                    \
+    else RTGS_LAUNCH(HAS_SH, BIG, RTGS_MAX_DEPTH, 1);                               \
+  } while (0)
   if (sh) { if (big) RTGS_LAUNCH_K(true, true); else RTGS_LAUNCH_K(true, false); }
   else    { if (big) RTGS_LAUNCH_K(false, true); else RTGS_LAUNCH_K(false, false); }
 #undef RTGS_LAUNCH_K

@@ -22,6 +22,8 @@ SH_COEFFS = 15
 TRACE_RESUME = 1
 TRACE_ACCUMULATE = 2
 TRACE_COMPACT = 4
+TRACE_SPLIT_ON = 8     # scheduling only: force / forbid two waves per 8x8 tile
+TRACE_SPLIT_OFF = 16
 
 LIB_PATH = os.environ.get("RTGS_HIP_LIB") or os.path.join(
     os.path.dirname(os.path.abspath(__file__)), "_lib", "librtgs_hip.so")

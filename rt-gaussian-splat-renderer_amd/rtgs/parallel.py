@@ -75,11 +75,17 @@ class HipBackend:
                                          nat.ptr(self.workspace), self.workspace.numel(),
                                          nat.stream()), "rtgs_project")
 
-    def trace(self, out, tile_first: int, tile_step: int, compact: bool, projected: bool = False):
+    def trace(self, out, tile_first: int, tile_step: int, compact: bool, projected: bool = False,
+              split=None):
+        """split: None = the library picks the kernel form by launch size; True / False force the
+        two-waves-per-tile / one-wave-per-tile form (same pixels either way)."""
         nat = self.nat
         order = self.tile_order(tile_first, tile_step) if self.use_tile_order else None
-        params = nat.RtgsTraceParams(self.depth, self.t_cutoff, tile_first, tile_step,
-                                     nat.TRACE_COMPACT if compact else 0, nat.ptr(order))
+        flags = nat.TRACE_COMPACT if compact else 0
+        if split is not None:
+            flags |= nat.TRACE_SPLIT_ON if split else nat.TRACE_SPLIT_OFF
+        params = nat.RtgsTraceParams(self.depth, self.t_cutoff, tile_first, tile_step, flags,
+                                     nat.ptr(order))
         nat.check(nat.lib().rtgs_trace(self.scene.native(), self.camera.native(), params,
                                        nat.ptr(out), None, None, 1, nat.ptr(self.workspace),
                                        self.workspace.numel(), 1 if projected else 0, nat.stream()),

@@ -194,6 +194,36 @@ def test_sharded_render_equals_whole_frame(world):
     assert torch.equal(tracer.sample_buf, whole)
 
 
+@pytest.mark.parametrize("name", ["c1", "oblique", "inside", "sh", "shallow", "large", "large_sh"])
+def test_two_waves_per_tile_form_is_bitwise_identical(name):
+    # launches of few tiles run TWO waves per 8x8 tile (alternate candidates, lists merged at the
+    # end; csrc/rtgs_trace.hip kSplit): scheduling only -- pixels, attenuation and ray.start must
+    # equal the one-wave form bit for bit, including depths below 16 and resumed partial samples
+    if name.startswith("large"):
+        w, h = 192, 108
+        arrays, cam, depth = synthetic.make_scene(270_000, w / h, 77, sh=name.endswith("sh")), synthetic.bench_camera(w, h), 16
+    else:
+        arrays, cam, depth = U.case(name)
+    _, _, tracer = U.build(arrays, cam)
+    outs = []
+    for flag in (nat.TRACE_SPLIT_OFF, nat.TRACE_SPLIT_ON):
+        per = []
+        part = max(2, depth // 3)
+        for d in (depth, part):
+            tracer.clear_sample()
+            tracer.trace(d, flags=flag)
+            per += [tracer.sample_buf.clone(), tracer.attenuation_buf.clone(),
+                    tracer.camera.cam_ray_field.start.clone()]
+            # the rest of the sample resumes from the first call's state
+            tracer.trace(max(2, depth - part), flags=flag | nat.TRACE_RESUME | nat.TRACE_ACCUMULATE)
+            per += [tracer.sample_buf.clone(), tracer.attenuation_buf.clone()]
+        outs.append(per)
+    torch.cuda.synchronize()
+    assert float(outs[0][0].abs().sum()) > 0
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_tile_parallel_renderer_single_rank():
     from rtgs.parallel import TileParallelRenderer
     arrays, cam, depth = U.case("c1")
