@@ -156,6 +156,14 @@ int rtgs_untile(const float* compact, int32_t world, int32_t tiles_per_rank, int
 int rtgs_closest_hit(const RtgsScene* scene, int32_t n_rays, const float* rays,
                      int32_t* hit_idx, float* hit_t, rtgs_stream_t stream);
 
+/* RayTracer.sample_step (ray_tracer.py:79-104) for an ARBITRARY ray field, literally: Scene.hit by
+ * brute force, Gaussian.eval at the chord midpoint (t1+t2)/2 along ray.direction, sample +=
+ * attenuation * alpha * rgb, attenuation *= 1 - alpha, ray.start = t1 + 1e-8 (+inf on a miss).
+ * The camera-ray fast path is rtgs_trace; this serves ray fields the caller has edited.
+ *   rays [n_rays][8] in/out (.start); sample_buf [n_rays][3] and attenuation_buf [n_rays] in/out. */
+int rtgs_sample_step_rays(const RtgsScene* scene, int32_t n_rays, float* rays, float* sample_buf,
+                          float* attenuation_buf, rtgs_stream_t stream);
+
 /* Gaussian.hit (gaussian.py:203-230), elementwise: ray k against Gaussian k. */
 int rtgs_gaussian_hit(int32_t n, const float* rays /*[n][8]*/, const float* position /*[n][3]*/,
                       const float* rotation /*[n][4]*/, const float* scale /*[n][3]*/,

@@ -432,6 +432,28 @@ def render_peel(scene, cam_position, cam_rotation, width, height, fx, fy, depth=
     return dict(sample=sample, attenuation=att, start=start, hits=hits)
 
 
+def sample_step_rays(scene, rays, sample, attenuation, absorb_eps=None):
+    """ray_tracer.py:79-104 on an ARBITRARY ray field, literally: rays (n, 8) = origin, direction,
+    start, end per ray; returns the updated (rays, sample, attenuation) copies.  One peel."""
+    dt = scene.dtype
+    if absorb_eps is None:
+        absorb_eps = dt == np.float64
+    rays = _a(rays, dt).reshape(-1, 8).copy()
+    sample = _a(sample, dt).reshape(-1, 3).copy()
+    att = _a(attenuation, dt).reshape(-1).copy()
+    origin, dirs = rays[:, 0:3], rays[:, 3:6]
+    idx, t1, t2 = closest_hit(scene, origin, dirs, rays[:, 6], rays[:, 7])
+    hit = idx >= 0
+    if hit.any():
+        h = np.nonzero(hit)[0]
+        rgb, alpha = _shade(scene, origin[h], dirs[h], idx[h], t1[h], t2[h])
+        sample[h] += (att[h] * alpha)[:, None] * rgb
+        att[h] *= dt(1) - alpha
+        rays[h, 6] = t1[h] if absorb_eps else (t1[h] + dt(EPS)).astype(dt)
+    rays[~hit, 6] = dt(np.inf)
+    return rays, sample, att
+
+
 def render_topk(scene, cam_position, cam_rotation, width, height, fx, fy, depth=16,
                 pixels=None, chunk=None, eps_q=1e-5, eps_t=1e-6):
     """SURVEY.md Appendix A.9 -- the one-pass form of the same image: the <= depth Gaussians

@@ -103,6 +103,43 @@ __device__ __forceinline__ HitD hit_quadratic(const double o[3], const double d[
 // One thread per ray; the workgroup streams (position, rotation, scale) = 40 B/Gaussian, builds
 // each slab's inverse covariances in fp64 and keeps the slab in LDS.  Brute force: the BVH of the reference only accelerates this query.
 constexpr int kHitBlock = 256;
+struct Closest { int idx; double t1, t2; };
+
+// Every thread of the workgroup must call this (barriers inside); `live` rays take part.
+__device__ __forceinline__ Closest closest_hit_block(int32_t n, const float* __restrict__ pos,
+                                                     const float* __restrict__ rot,
+                                                     const float* __restrict__ scale, bool live,
+                                                     const double o[3], const double d[3], float start,
+                                                     float end, float* s_mu, double* s_m) {
+  const double inf = __builtin_huge_val();
+  Closest c{-1, inf, inf};
+  for (int base = 0; base < n; base += kHitBlock) {
+    const int cnt = min(kHitBlock, n - base);
+    __syncthreads();
+    if ((int)threadIdx.x < cnt) {
+      const int g = base + threadIdx.x;
+      float* s = s_mu + threadIdx.x * 3;
+      s[0] = pos[3 * g]; s[1] = pos[3 * g + 1]; s[2] = pos[3 * g + 2];
+      cov_inverse6(rot + 4 * (size_t)g, scale + 3 * (size_t)g, s_m + threadIdx.x * 6);
+    }
+    __syncthreads();
+    if (live) {
+      for (int k = 0; k < cnt; ++k) {
+        const HitD h = hit_quadratic(o, d, s_mu + k * 3, s_m + k * 6);
+        // scene.py:433-436: start < t1 < end, strictly smaller than the best so far.  The window
+        // is tested on t1 ROUNDED TO FP32, the precision ray.start has: sample_step stores
+        // start = t1 + 1e-8 = t1 in fp32 (ray_tracer.py:99-102), and the strict '>' must then
+        // exclude that same Gaussian on the next peel, as it does in the all-fp32 reference.
+        const float t1f = (float)h.t1;
+        if (t1f < end && t1f > start && h.t1 < c.t1) {
+          c.t1 = h.t1; c.t2 = h.t2; c.idx = base + k;
+        }
+      }
+    }
+  }
+  return c;
+}
+
 __global__ __launch_bounds__(kHitBlock) void k_closest_hit(int32_t n, const float* __restrict__ pos,
                                                             const float* __restrict__ rot,
                                                             const float* __restrict__ scale,
@@ -122,34 +159,61 @@ __global__ __launch_bounds__(kHitBlock) void k_closest_hit(int32_t n, const floa
     d[0] = rp[3]; d[1] = rp[4]; d[2] = rp[5];
     start = rp[6]; end = rp[7];
   }
-  const double inf = __builtin_huge_val();
-  double best_t = inf, best_t2 = inf;
-  int best = -1;
-  for (int base = 0; base < n; base += kHitBlock) {
-    const int cnt = min(kHitBlock, n - base);
-    __syncthreads();
-    if ((int)threadIdx.x < cnt) {
-      const int g = base + threadIdx.x;
-      float* s = s_mu + threadIdx.x * 3;
-      s[0] = pos[3 * g]; s[1] = pos[3 * g + 1]; s[2] = pos[3 * g + 2];
-      cov_inverse6(rot + 4 * (size_t)g, scale + 3 * (size_t)g, s_m + threadIdx.x * 6);
-    }
-    __syncthreads();
-    if (live) {
-      for (int k = 0; k < cnt; ++k) {
-        const HitD h = hit_quadratic(o, d, s_mu + k * 3, s_m + k * 6);
-        // scene.py:433-436: start < t1 < end, strictly smaller than the best so far
-        if (h.t1 < (double)end && h.t1 > (double)start && h.t1 < best_t) {
-          best_t = h.t1; best_t2 = h.t2; best = base + k;
-        }
-      }
-    }
-  }
+  const Closest c = closest_hit_block(n, pos, rot, scale, live, o, d, start, end, s_mu, s_m);
   if (live) {
-    hit_idx[r] = best;
-    hit_t[2 * r] = (float)best_t;
-    hit_t[2 * r + 1] = (float)best_t2;
+    hit_idx[r] = c.idx;
+    hit_t[2 * r] = (float)c.t1;
+    hit_t[2 * r + 1] = (float)c.t2;
   }
+}
+
+__device__ __forceinline__ void gaussian_eval_d(const double p[3], const double dir[3], const float* mu,
+                                                const float* rot, const float* scale, const float* colop,
+                                                const float* sh, double out[4]);
+
+// ---- RayTracer.sample_step for an ARBITRARY ray field (ray_tracer.py:79-104, literally) -------
+// Scene.hit by brute force, Gaussian.eval at the chord midpoint, accumulate, advance ray.start.
+// The camera-ray fast path is k_trace (csrc/rtgs_trace.hip); this one serves ray fields the
+// caller has edited, which k_trace cannot assume anything about.
+__global__ __launch_bounds__(kHitBlock) void k_sample_step_rays(int32_t n, const float* __restrict__ pos,
+                                                                 const float* __restrict__ rot,
+                                                                 const float* __restrict__ scale,
+                                                                 const float* __restrict__ colop,
+                                                                 const float* __restrict__ sh,
+                                                                 int32_t n_rays, float* __restrict__ rays,
+                                                                 float* __restrict__ sample,
+                                                                 float* __restrict__ att) {
+  __shared__ float s_mu[kHitBlock * 3];
+  __shared__ double s_m[kHitBlock * 6];
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = r < n_rays;
+  double o[3] = {0, 0, 0}, d[3] = {0, 1, 0};
+  float start = 0.f, end = kInf;
+  float* rp = rays + (size_t)r * RTGS_RAY_FLOATS;
+  if (live) {
+    o[0] = rp[0]; o[1] = rp[1]; o[2] = rp[2];
+    d[0] = rp[3]; d[1] = rp[4]; d[2] = rp[5];
+    start = rp[6]; end = rp[7];
+  }
+  const Closest c = closest_hit_block(n, pos, rot, scale, live, o, d, start, end, s_mu, s_m);
+  if (!live) return;
+  if (c.idx < 0) {
+    rp[6] = kInf;   // ray_tracer.py:103-104
+    return;
+  }
+  const double tm = (c.t1 + c.t2) / 2.0;   // ray_tracer.py:90-91
+  const double p[3] = {o[0] + tm * d[0], o[1] + tm * d[1], o[2] + tm * d[2]};
+  const size_t g = (size_t)c.idx;
+  double e[4];
+  gaussian_eval_d(p, d, pos + 3 * g, rot + 4 * g, scale + 3 * g, colop + 4 * g,
+                  sh ? sh + g * RTGS_SH_COEFFS * 3 : nullptr, e);
+  const float a = att[r];
+  const float alpha = (float)e[3];
+  sample[3 * (size_t)r + 0] += a * alpha * (float)e[0];   // ray_tracer.py:95-97
+  sample[3 * (size_t)r + 1] += a * alpha * (float)e[1];
+  sample[3 * (size_t)r + 2] += a * alpha * (float)e[2];
+  att[r] = a * (1.0f - alpha);
+  rp[6] = (float)c.t1 + 1e-8f;   // ray_tracer.py:99-102 (absorbed in fp32 for t1 > ~0.17)
 }
 
 // ---- Gaussian.hit, elementwise ----------------------------------------------------------
@@ -170,27 +234,20 @@ __global__ __launch_bounds__(256) void k_gaussian_hit(int32_t n, const float* __
   hit_t[2 * k + 1] = (float)h.t2;
 }
 
-// ---- Gaussian.eval + eval_sh (gaussian.py:140-201), elementwise, fp64 inside -------------
-__global__ __launch_bounds__(256) void k_gaussian_eval(int32_t n, const float* __restrict__ pos,
-                                                        const float* __restrict__ dir,
-                                                        const float* __restrict__ mu,
-                                                        const float* __restrict__ rot,
-                                                        const float* __restrict__ scale,
-                                                        const float* __restrict__ colop,
-                                                        const float* __restrict__ sh,
-                                                        float* __restrict__ out) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n) return;
-  const double x = (double)pos[3 * k] - mu[3 * k], y = (double)pos[3 * k + 1] - mu[3 * k + 1],
-               z = (double)pos[3 * k + 2] - mu[3 * k + 2];
+// ---- Gaussian.eval + eval_sh (gaussian.py:140-201), fp64 inside -----------------------------
+// out = (rgb, alpha) of Gaussian (mu, rot, scale, colop[, sh]) at point p seen along dir.
+__device__ __forceinline__ void gaussian_eval_d(const double p[3], const double dir[3], const float* mu,
+                                                const float* rot, const float* scale, const float* colop,
+                                                const float* sh, double out[4]) {
+  const double x = p[0] - (double)mu[0], y = p[1] - (double)mu[1], z = p[2] - (double)mu[2];
   double c[6];
-  cov_inverse6(rot + 4 * (size_t)k, scale + 3 * (size_t)k, c);
+  cov_inverse6(rot, scale, c);
   const double q = x * (c[0] * x + c[1] * y + c[2] * z) + y * (c[1] * x + c[3] * y + c[4] * z) +
                    z * (c[2] * x + c[4] * y + c[5] * z);
   const double rho = exp(-q);  // no 1/2 factor: gaussian.py:197
-  double rgb[3] = {colop[4 * k], colop[4 * k + 1], colop[4 * k + 2]};
+  double rgb[3] = {colop[0], colop[1], colop[2]};
   if (sh) {
-    double dx = dir[3 * k], dy = dir[3 * k + 1], dz = dir[3 * k + 2];
+    double dx = dir[0], dy = dir[1], dz = dir[2];
     const double il = 1.0 / sqrt(dx * dx + dy * dy + dz * dz);  // gaussian.py:200
     dx *= il; dy *= il; dz *= il;
     const double c0 = sqrt(3.0 / M_PI), c1 = sqrt(15.0 / M_PI), c2 = sqrt(5.0 / M_PI),
@@ -203,13 +260,31 @@ __global__ __launch_bounds__(256) void k_gaussian_eval(int32_t n, const float* _
         0.25 * c5 * dy * (5 * dz * dz - 1), 0.25 * c6 * (5 * dz * dz - 3 * dz) /* sic, :160 */,
         0.25 * c5 * dx * (5 * dz * dz - 1), 0.25 * c4 * (dx * dx - dy * dy) * dz,
         0.25 * c3 * dx * (dx * dx - 3 * dy * dy)};
-    const float* s = sh + (size_t)k * RTGS_SH_COEFFS * 3;
     for (int b = 0; b < RTGS_SH_COEFFS; ++b) {
-      rgb[0] += Y[b] * s[3 * b]; rgb[1] += Y[b] * s[3 * b + 1]; rgb[2] += Y[b] * s[3 * b + 2];
+      rgb[0] += Y[b] * sh[3 * b]; rgb[1] += Y[b] * sh[3 * b + 1]; rgb[2] += Y[b] * sh[3 * b + 2];
     }
   }
-  out[4 * k] = (float)rgb[0]; out[4 * k + 1] = (float)rgb[1]; out[4 * k + 2] = (float)rgb[2];
-  out[4 * k + 3] = (float)((double)colop[4 * k + 3] * rho);
+  out[0] = rgb[0]; out[1] = rgb[1]; out[2] = rgb[2];
+  out[3] = (double)colop[3] * rho;
+}
+
+__global__ __launch_bounds__(256) void k_gaussian_eval(int32_t n, const float* __restrict__ pos,
+                                                        const float* __restrict__ dir,
+                                                        const float* __restrict__ mu,
+                                                        const float* __restrict__ rot,
+                                                        const float* __restrict__ scale,
+                                                        const float* __restrict__ colop,
+                                                        const float* __restrict__ sh,
+                                                        float* __restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const double p[3] = {pos[3 * k], pos[3 * k + 1], pos[3 * k + 2]};
+  const double d[3] = {dir[3 * k], dir[3 * k + 1], dir[3 * k + 2]};
+  double o[4];
+  gaussian_eval_d(p, d, mu + 3 * (size_t)k, rot + 4 * (size_t)k, scale + 3 * (size_t)k,
+                  colop + 4 * (size_t)k, sh ? sh + (size_t)k * RTGS_SH_COEFFS * 3 : nullptr, o);
+  out[4 * k] = (float)o[0]; out[4 * k + 1] = (float)o[1]; out[4 * k + 2] = (float)o[2];
+  out[4 * k + 3] = (float)o[3];
 }
 
 // ---- quaternion helpers, literal fp32 (utils/quaternion.py) -------------------------------
@@ -309,6 +384,19 @@ int rtgs_closest_hit(const RtgsScene* scene, int32_t n_rays, const float* rays, 
   hipLaunchKernelGGL(k_closest_hit, grid_for(n_rays, kHitBlock), dim3(kHitBlock), 0,
                      static_cast<hipStream_t>(stream), scene->n, scene->position, scene->rotation,
                      scene->scale, n_rays, rays, hit_idx, hit_t);
+  return check_launch();
+}
+
+int rtgs_sample_step_rays(const RtgsScene* scene, int32_t n_rays, float* rays, float* sample_buf,
+                          float* attenuation_buf, rtgs_stream_t stream) {
+  if (!scene || scene->n <= 0 || !scene->position || !scene->rotation || !scene->scale ||
+      !scene->color_opacity || n_rays < 0 || !rays || !sample_buf || !attenuation_buf)
+    return RTGS_EINVAL;
+  if (n_rays == 0) return RTGS_OK;
+  hipLaunchKernelGGL(k_sample_step_rays, grid_for(n_rays, kHitBlock), dim3(kHitBlock), 0,
+                     static_cast<hipStream_t>(stream), scene->n, scene->position, scene->rotation,
+                     scene->scale, scene->color_opacity, scene->sh, n_rays, rays, sample_buf,
+                     attenuation_buf);
   return check_launch();
 }
 

@@ -62,6 +62,7 @@ PROTOTYPES = {
     "rtgs_untile": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "rtgs_closest_hit": (c_int32, [POINTER(RtgsScene), c_int32, c_void_p, c_void_p, c_void_p,
                                    c_void_p]),
+    "rtgs_sample_step_rays": (c_int32, [POINTER(RtgsScene), c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rtgs_gaussian_hit": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p]),
     "rtgs_gaussian_eval": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -24,9 +24,11 @@ class Camera:
         if self.buf_size.x <= 0 or self.buf_size.y <= 0:
             raise ValueError("buf_size must be positive")
         self.cam_ray_field = Ray.field(shape=(self.buf_size.x, self.buf_size.y))
+        self.cam_ray_field.mark_edited(False)   # stands for this camera's rays until someone edits it
         # pose the ray field was last generated for: what sample_step traces
         self.field_position = vec3(position)
         self.field_rotation = vec4(rotation)
+        self.cam_ray_field.mark_edited(False)
 
     def native(self, position=None, rotation=None) -> nat.RtgsCamera:
         return nat.make_camera(self.position if position is None else position,
@@ -54,3 +56,4 @@ class Camera:
                   "rtgs_generate_rays")
         self.field_position = vec3(position)
         self.field_rotation = vec4(rotation)
+        self.cam_ray_field.mark_edited(False)

@@ -63,7 +63,12 @@ class Ray:
 
 
 class RayField:
-    """A (shape..., 8) float32 device tensor of rays; element [I] is a ``Ray``."""
+    """A (shape..., 8) float32 device tensor of rays; element [I] is a ``Ray``.
+
+    ``edited`` records whether the field may differ from what ``Camera.generate_ray_field`` last
+    wrote (element assignment and ``init`` set it; writes through ``.data`` or the component
+    views cannot be seen -- call ``mark_edited()`` after those).  ``RayTracer.sample_step`` picks
+    its kernel by it."""
 
     def __init__(self, shape, data: torch.Tensor | None = None):
         self.shape = (shape,) if isinstance(shape, int) else tuple(int(s) for s in shape)
@@ -71,12 +76,17 @@ class RayField:
             data = torch.zeros(self.shape + (nat.RAY_FLOATS,), dtype=torch.float32,
                                device=nat.device())
         self.data = nat.require_device(data, "ray field")
+        self.edited = True      # not (yet) a generated camera ray field
+
+    def mark_edited(self, edited: bool = True) -> None:
+        self.edited = bool(edited)
 
     def init(self, origin=(0, 0, 0), direction=(0, 1, 0), start=0, end=math.inf):
         """Run ``Ray.init`` (ray.py:20-41) on every element."""
         proto = Ray()
         proto.init(origin, direction, start, end)
         self.data[...] = torch.from_numpy(proto.as_array()).to(self.data.device)
+        self.edited = True
 
     def get(self, t) -> torch.Tensor:
         """``Ray.get`` (ray.py:43-52) elementwise; t broadcasts against the field shape."""
@@ -100,6 +110,7 @@ class RayField:
 
     def __setitem__(self, idx, ray: Ray):
         self.data[idx] = torch.from_numpy(ray.as_array()).to(self.data.device)
+        self.edited = True
 
     def to_numpy(self) -> np.ndarray:
         return self.data.cpu().numpy()

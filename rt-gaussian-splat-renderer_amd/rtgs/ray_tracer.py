@@ -82,9 +82,26 @@ class RayTracer:
 
     def sample_step(self):
         """Composite the next-nearest Gaussian of every pixel (ray_tracer.py:79-104), resuming
-        from ``cam_ray_field.start`` / ``attenuation_buf`` and accumulating into ``sample_buf``."""
+        from ``cam_ray_field.start`` / ``attenuation_buf`` and accumulating into ``sample_buf``.
+
+        A ray field that still holds what ``generate_ray_field`` wrote takes the screen-space
+        kernel (``rtgs_trace``); one the caller has edited (``cam_ray_field[i, j] = ray``,
+        ``.init()``, ``.mark_edited()``) is traced ray by ray as the reference does, whatever the
+        rays are (``rtgs_sample_step_rays``)."""
+        if self.camera.cam_ray_field.edited:
+            self.sample_step_rays()
+            return
         self.trace(1, flags=nat.TRACE_RESUME | nat.TRACE_ACCUMULATE,
                    position=self.camera.field_position, rotation=self.camera.field_rotation)
+
+    def sample_step_rays(self):
+        """The literal per-ray form of ``sample_step``: brute-force ``Scene.hit`` of every ray of
+        ``cam_ray_field`` exactly as stored (origin, direction, start, end)."""
+        rays = self.camera.cam_ray_field.data
+        n = self.buf_size.x * self.buf_size.y
+        nat.check(nat.lib().rtgs_sample_step_rays(self.scene.native(), n, nat.ptr(rays),
+                                                  nat.ptr(self.sample_buf), nat.ptr(self.attenuation_buf),
+                                                  nat.stream()), "rtgs_sample_step_rays")
 
     def sample_all(self, depth: int, t_cutoff: float = 0.0):
         """Extension: one WHOLE sample (``depth`` peels) in a single launch -- the result of

@@ -167,6 +167,75 @@ def test_transmittance_cutoff_changes_little():
     assert float((a.sample_buf - b.sample_buf).abs().max()) <= 5e-5
 
 
+# ---- edited ray fields: the literal per-ray sample_step (ray_tracer.py:79-104) ----
+
+def _edited_field_case(sh):
+    arrays = synthetic.make_scene(700, 1.0, 321, sh=sh)
+    cam = synthetic.bench_camera(24, 20)
+    _, camera, tracer = U.build(arrays, cam)
+    camera.generate_ray_field(camera.position, camera.rotation)
+    rays = camera.cam_ray_field.to_numpy().reshape(-1, 8).copy()
+    rng = np.random.default_rng(9)
+    n = rays.shape[0]
+    # a third of the rays from another viewpoint, a third with unnormalised / tilted directions,
+    # some with a finite [start, end] window, one with zero direction (hits nothing)
+    k = n // 3
+    rays[:k, 0:3] = np.float32([0.4, -0.3, 2.5])
+    rays[k:2 * k, 3:6] = (rays[k:2 * k, 3:6] * 1.7 + rng.normal(0, 0.05, (k, 3))).astype(np.float32)
+    rays[2 * k:2 * k + 40, 6] = 1.6
+    rays[2 * k + 20:2 * k + 80, 7] = 2.4
+    rays[-1, 3:6] = 0.0
+    return arrays, camera, tracer, rays
+
+
+@pytest.mark.parametrize("sh", [False, True])
+def test_edited_ray_field_is_traced_ray_by_ray(sh):
+    from oracle import rtgs_ref as ref
+    arrays, camera, tracer, rays = _edited_field_case(sh)
+    w, h = camera.buf_size.x, camera.buf_size.y
+    camera.cam_ray_field.data.copy_(torch.from_numpy(rays.reshape(w, h, 8)))
+    assert not camera.cam_ray_field.edited
+    camera.cam_ray_field.mark_edited()
+    tracer.clear_sample(); tracer.clear_attenuation()
+    osc = ref.OracleScene(**arrays)
+    want = (rays.astype(np.float64), np.zeros((w * h, 3)), np.ones(w * h))
+    for step in range(4):
+        tracer.sample_step()
+        want = ref.sample_step_rays(osc, *want)
+    torch.cuda.synchronize()
+    got_s = tracer.sample_buf.cpu().numpy().reshape(-1, 3)
+    got_a = tracer.attenuation_buf.cpu().numpy().reshape(-1)
+    got_start = camera.cam_ray_field.to_numpy().reshape(-1, 8)[:, 6]
+    assert np.abs(got_s - want[1]).max() <= 2e-6 and np.abs(got_a - want[2]).max() <= 2e-6
+    fin = np.isfinite(want[0][:, 6])
+    assert (np.isfinite(got_start) == fin).all() and np.abs(got_start[fin] - want[0][fin, 6]).max() <= 1e-6
+    assert np.isinf(got_start[-1]) and float(np.abs(got_s).sum()) > 0
+    # element assignment marks the field as edited by itself; generate_ray_field clears the mark
+    camera.generate_ray_field(camera.position, camera.rotation)
+    assert not camera.cam_ray_field.edited
+    camera.cam_ray_field[3, 4] = rtgs.new_ray((0, 0, 3), (0, 0, -1))
+    assert camera.cam_ray_field.edited
+
+
+def test_per_ray_and_screen_space_sample_steps_agree_on_camera_rays():
+    # same rays, two kernels: the brute-force per-ray path against the screen-space fast path
+    arrays, cam, depth = U.case("c1")
+    _, camera, fast = U.build(arrays, cam)
+    _, camera2, slow = U.build(arrays, cam)
+    for _ in range(3):
+        fast.sample(depth)
+    camera2.generate_ray_field(camera2.position, camera2.rotation)
+    camera2.cam_ray_field.mark_edited()
+    slow.clear_attenuation()
+    for _ in range(3):
+        slow.sample_step()
+    torch.cuda.synchronize()
+    g = U.golden("c1_full")
+    solid = ~g["fragile"]
+    d = (fast.sample_buf - slow.sample_buf).abs().cpu().numpy()
+    assert d[g["pixels"][:, 0], g["pixels"][:, 1]][solid].max() <= U.PIXEL_TOL
+
+
 # ---- sharding ----
 
 @pytest.mark.parametrize("world", [2, 3, 8])

@@ -54,6 +54,32 @@ def test_peeling_can_be_resumed(small):
     assert np.array_equal(full["sample"], want["sample"]) and np.array_equal(full["start"], want["start"])
 
 
+def test_per_ray_sample_step_equals_the_camera_peel(small):
+    # sample_step_rays is the same loop body fed from a stored ray field (ray_tracer.py:79-104):
+    # on the camera's own rays, k calls must reproduce k peels of render_peel exactly
+    arrays, cam = small
+    osc = ref.OracleScene(**arrays)
+    origin, dirs = ref.generate_rays(cam["position"], cam["rotation"], cam["width"], cam["height"],
+                                     cam["fx"], cam["fy"])
+    n = dirs.shape[0]
+    rays = np.concatenate([np.broadcast_to(origin, (n, 3)), dirs, np.zeros((n, 1)), np.full((n, 1), np.inf)], axis=1)
+    sample, att = np.zeros((n, 3)), np.ones(n)
+    for _ in range(5):
+        rays, sample, att = ref.sample_step_rays(osc, rays, sample, att)
+    want = peel(arrays, cam, 16, steps=5)
+    # (per-ray origins go through the general branch of the hit arithmetic: equal to rounding)
+    assert np.abs(sample - want["sample"]).max() < 1e-12 and np.abs(att - want["attenuation"]).max() < 1e-12
+    fin = np.isfinite(want["start"])
+    assert (np.isfinite(rays[:, 6]) == fin).all() and np.abs(rays[fin, 6] - want["start"][fin]).max() < 1e-12
+    # ray.end cuts the search: with end just past the first hit only that hit is found
+    first = peel(arrays, cam, 16, steps=1)
+    rays2 = rays.copy(); rays2[:, 6] = 0.0
+    rays2[:, 7] = np.where(np.isfinite(first["start"]), first["start"] + 1e-9, 1.0)
+    r2, s2, a2 = ref.sample_step_rays(osc, rays2, np.zeros((n, 3)), np.ones(n))
+    r3, s3, a3 = ref.sample_step_rays(osc, r2, s2, a2)
+    assert np.abs(s2 - first["sample"]).max() < 1e-12 and np.array_equal(s3, s2) and np.isinf(r3[:, 6]).all()
+
+
 def test_gaussian_order_is_irrelevant(small):
     arrays, cam = small
     perm = np.random.default_rng(5).permutation(arrays["position"].shape[0])
