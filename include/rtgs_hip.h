@@ -109,6 +109,11 @@ int rtgs_covariance(int32_t n, const float* rotation /*[n][4]*/, const float* sc
                     float* cov6 /*[n][6] or NULL*/, float* cov_inv6 /*[n][6]*/,
                     rtgs_stream_t stream);
 
+/* The same under the name and argument list SURVEY.md 8(b) gives it: sigma_inv6 [n][6] only
+ * (position is accepted and unused: the inverse covariance does not depend on it). */
+int rtgs_precompute(int32_t n, const float* position /*[n][3]*/, const float* rotation /*[n][4]*/,
+                    const float* scale /*[n][3]*/, float* sigma_inv6 /*[n][6]*/, rtgs_stream_t stream);
+
 /* Camera.generate_ray_field (camera.py:57-71): rays[(i*H + j)*8 ..] = {o, d, 0, +inf}. */
 int rtgs_generate_rays(const RtgsCamera* cam, float* rays /*[W][H][8]*/, rtgs_stream_t stream);
 
@@ -143,6 +148,14 @@ int rtgs_trace(const RtgsScene* scene, const RtgsCamera* cam, const RtgsTracePar
  * quadratic of gaussian.py:215-219, factored per Gaussian instead of per ray). */
 int rtgs_project(const RtgsScene* scene, const RtgsCamera* cam, void* workspace,
                  size_t workspace_bytes, rtgs_stream_t stream);
+
+/* One-call form of a whole sample (SURVEY.md 8(b) signature): rtgs_project + rtgs_trace of the
+ * macro-tile ROWS [tile_y0, tile_y1) (rows of rtgs_tile_size() pixels in j; all rows = 0 ..
+ * ceil(H / tile)) into the (W,H,3) image sample_out, overwriting those rows' pixels; the other
+ * pixels are not touched.  transmittance_out: optional (W,H) plane. */
+int rtgs_render(const RtgsScene* scene, const RtgsCamera* cam, int32_t depth, float t_cutoff,
+                int32_t tile_y0, int32_t tile_y1, float* sample_out, float* transmittance_out,
+                void* workspace, size_t workspace_bytes, rtgs_stream_t stream);
 
 /* Tile-parallel epilogue: scatter gathered shard-compact buffers
  * compact[rank][local_tile][T][T][3], T = rtgs_tile_size(), (rank-major, `tiles_per_rank` tiles each, as produced

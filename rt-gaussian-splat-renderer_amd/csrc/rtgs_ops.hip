@@ -369,6 +369,12 @@ int rtgs_covariance(int32_t n, const float* rotation, const float* scale, float*
   return check_launch();
 }
 
+int rtgs_precompute(int32_t n, const float* position, const float* rotation, const float* scale,
+                    float* sigma_inv6, rtgs_stream_t stream) {
+  (void)position;   // the inverse covariance does not depend on it; kept for the SURVEY 8(b) signature
+  return rtgs_covariance(n, rotation, scale, nullptr, sigma_inv6, stream);
+}
+
 int rtgs_generate_rays(const RtgsCamera* cam, float* rays, rtgs_stream_t stream) {
   if (!cam || !rays || cam->width <= 0 || cam->height <= 0 || !(cam->fx > 0.f) || !(cam->fy > 0.f))
     return RTGS_EINVAL;

@@ -920,17 +920,22 @@ int rtgs_project(const RtgsScene* scene, const RtgsCamera* cam, void* workspace,
   return check_launch();
 }
 
-int rtgs_trace(const RtgsScene* scene, const RtgsCamera* cam, const RtgsTraceParams* params,
-               float* sample_buf, float* attenuation_buf, float* ray_start,
-               int32_t ray_start_stride, void* workspace, size_t workspace_bytes,
-               int32_t projected, rtgs_stream_t stream) {
+}  // extern "C"
+
+// tile_limit caps the number of (tile_first, tile_step) tiles the launch covers (rtgs_render's
+// row ranges); rtgs_trace passes "all of them".
+static int trace_impl(const RtgsScene* scene, const RtgsCamera* cam, const RtgsTraceParams* params,
+                      float* sample_buf, float* attenuation_buf, float* ray_start,
+                      int32_t ray_start_stride, void* workspace, size_t workspace_bytes,
+                      int32_t projected, int32_t tile_limit, rtgs_stream_t stream) {
   if (!params || !sample_buf) return RTGS_EINVAL;
   if (int rc = validate(scene, cam, workspace, workspace_bytes)) return rc;
   if (params->depth < 1 || params->depth > RTGS_MAX_DEPTH) return RTGS_EDEPTH;
   if (params->tile_step <= 0 || params->tile_first < 0 || !(params->t_cutoff >= 0.f)) return RTGS_EINVAL;
   if ((params->flags & RTGS_TRACE_RESUME) && (!attenuation_buf || !ray_start)) return RTGS_EINVAL;
   if (ray_start && ray_start_stride <= 0) return RTGS_EINVAL;
-  const int32_t local = rtgs_num_local_tiles(cam->width, cam->height, params->tile_first, params->tile_step);
+  int32_t local = rtgs_num_local_tiles(cam->width, cam->height, params->tile_first, params->tile_step);
+  if (local > tile_limit) local = tile_limit;
   if (local <= 0) return RTGS_OK;  // a shard with no tiles
   if (!projected)
     if (int rc = rtgs_project(scene, cam, workspace, workspace_bytes, stream)) return rc;
@@ -984,6 +989,34 @@ int rtgs_trace(const RtgsScene* scene, const RtgsCamera* cam, const RtgsTracePar
 #undef RTGS_LAUNCH_K
 #undef RTGS_LAUNCH
   return check_launch();
+}
+
+extern "C" {
+
+int rtgs_trace(const RtgsScene* scene, const RtgsCamera* cam, const RtgsTraceParams* params,
+               float* sample_buf, float* attenuation_buf, float* ray_start,
+               int32_t ray_start_stride, void* workspace, size_t workspace_bytes,
+               int32_t projected, rtgs_stream_t stream) {
+  return trace_impl(scene, cam, params, sample_buf, attenuation_buf, ray_start, ray_start_stride,
+                    workspace, workspace_bytes, projected, INT32_MAX, stream);
+}
+
+int rtgs_render(const RtgsScene* scene, const RtgsCamera* cam, int32_t depth, float t_cutoff,
+                int32_t tile_y0, int32_t tile_y1, float* sample_out, float* transmittance_out,
+                void* workspace, size_t workspace_bytes, rtgs_stream_t stream) {
+  if (!cam || cam->width <= 0 || cam->height <= 0) return RTGS_EINVAL;
+  const int32_t tiles_x = (cam->width + kTile - 1) / kTile, tiles_y = (cam->height + kTile - 1) / kTile;
+  if (tile_y0 < 0 || tile_y1 > tiles_y || tile_y0 > tile_y1) return RTGS_EINVAL;
+  if (tile_y0 == tile_y1) return RTGS_OK;
+  RtgsTraceParams p;
+  p.depth = depth;
+  p.t_cutoff = t_cutoff;
+  p.tile_first = tile_y0 * tiles_x;
+  p.tile_step = 1;
+  p.flags = 0;
+  p.tile_order = nullptr;
+  return trace_impl(scene, cam, &p, sample_out, transmittance_out, nullptr, 1, workspace, workspace_bytes,
+                    0, (tile_y1 - tile_y0) * tiles_x, stream);
 }
 
 int rtgs_untile(const float* compact, int32_t world, int32_t tiles_per_rank, int32_t width,

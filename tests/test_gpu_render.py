@@ -386,6 +386,40 @@ def test_error_codes_become_exceptions():
         rtgs.RayTracer((8, 8), scene, camera)
 
 
+def test_one_call_render_and_precompute_entry_points():
+    # SURVEY.md 8(b)'s names: rtgs_render (whole sample of a range of macro-tile rows in one call)
+    # and rtgs_precompute (inverse covariances) are thin forms of rtgs_project + rtgs_trace and
+    # rtgs_covariance; same bits
+    arrays, cam, depth = U.case("oblique")
+    scene, camera, tracer = U.build(arrays, cam)
+    tracer.trace(depth)
+    whole, att = tracer.sample_buf.clone(), tracer.attenuation_buf.clone()
+    lib, ws = nat.lib(), tracer._ws()
+    T = nat.tile_size()
+    rows = (cam["height"] + T - 1) // T
+    img = torch.full_like(whole, -1.0)
+    trans = torch.full_like(att, -1.0)
+    cuts = [0, 1, rows // 2, rows]
+    for y0, y1 in zip(cuts[:-1], cuts[1:]):
+        nat.check(lib.rtgs_render(scene.native(), camera.native(), depth, 0.0, y0, y1, nat.ptr(img),
+                                  nat.ptr(trans), nat.ptr(ws), ws.numel(), nat.stream()))
+        torch.cuda.synchronize()
+        done = min(y1 * T, cam["height"])
+        assert torch.equal(img[:, :done], whole[:, :done]) and bool((img[:, done:] == -1.0).all())
+    assert torch.equal(img, whole) and torch.equal(trans, att)
+    assert lib.rtgs_render(scene.native(), camera.native(), depth, 0.0, 0, rows + 1, nat.ptr(img), None,
+                           nat.ptr(ws), ws.numel(), nat.stream()) == -1
+    assert lib.rtgs_render(scene.native(), camera.native(), 17, 0.0, 0, rows, nat.ptr(img), None,
+                           nat.ptr(ws), ws.numel(), nat.stream()) == -2
+    n = scene.num_gaussians
+    a = torch.empty((n, 6), device="cuda"); b = torch.empty((n, 6), device="cuda")
+    nat.check(lib.rtgs_covariance(n, nat.ptr(scene.rotation), nat.ptr(scene.scale), None, nat.ptr(a), nat.stream()))
+    nat.check(lib.rtgs_precompute(n, nat.ptr(scene.position), nat.ptr(scene.rotation), nat.ptr(scene.scale),
+                                  nat.ptr(b), nat.stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+
+
 class _FakeWork:
     def wait(self):
         return True
