@@ -48,9 +48,6 @@ namespace {
 #ifndef RTGS_REC_MODE
 #define RTGS_REC_MODE 1   // 1: scalar record loads where first needed; 3: whole record up front
 #endif
-#ifndef RTGS_INSERT
-#define RTGS_INSERT 3     // 3: chain-free compare/select insertion; 1: v_cmpx/v_swap serial bubble
-#endif
 #ifndef RTGS_STAMPS
 #define RTGS_STAMPS 0     // diagnostic build: per-phase s_memtime stamps of wave 0 into the buffer
 #endif                    // passed as attenuation_buf (8 x u64 per block); never quote its run time
@@ -59,6 +56,9 @@ namespace {
 #endif                    // 3 no per-candidate loop, 4 no slab expansion either
 #ifndef RTGS_WAVES_PER_SIMD
 #define RTGS_WAVES_PER_SIMD 4   // __launch_bounds__ second argument: caps VGPRs at 512/this
+#endif
+#ifndef RTGS_WAVES_PER_SIMD_MAIN
+#define RTGS_WAVES_PER_SIMD_MAIN 5   // the whole-frame instantiation (no SH, <= 4096 slabs): 96 VGPRs
 #endif
 #ifndef RTGS_WAVES_PER_SIMD_SH
 #define RTGS_WAVES_PER_SIMD_SH 4   // the SH variant carries 15 basis values more per lane
@@ -90,7 +90,7 @@ struct Tune {
 #endif
 constexpr int kBigSceneSlabs = RTGS_BIG_SLABS;   // scenes with more slabs than this use Tune<true>
 #ifndef RTGS_SPLIT_MAX_TILES
-#define RTGS_SPLIT_MAX_TILES 1024
+#define RTGS_SPLIT_MAX_TILES 832
 #endif
 constexpr int kSplitMaxTiles = RTGS_SPLIT_MAX_TILES;
 #ifndef RTGS_SUPER
@@ -101,6 +101,17 @@ constexpr int kSplitMaxTiles = RTGS_SPLIT_MAX_TILES;
 // lifetime (every one of 32 400 workgroups streaming 250 KB of bounds through L2); c3 (1.6 k slabs)
 // is faster flat (one barrier less), so Tune<false> keeps the flat scan.
 constexpr int kSuper = RTGS_SUPER;
+// A tile's surviving slabs are visited nearest first (by k_project's depth key) when there are at
+// most kSortMax of them -- the same bound for every instantiation.  In stream (Morton) order near
+// and far Gaussians interleave and nearly EVERY candidate inserts into some lane's list; nearest
+// first, the lists fill with near entries and far candidates are rejected wave-wide: 56 -> 44
+// inserting candidates on c3's central 8x8 tiles (simulated with the oracle; sorting single
+// Gaussians exactly would give 43.5).  Pixels do not depend on the order (see list_insert_par).
+#ifndef RTGS_SORT_MAX
+#define RTGS_SORT_MAX 256
+#endif
+constexpr int kSortMax = RTGS_SORT_MAX;
+
 
 struct TraceArgs {
   int32_t n;
@@ -117,6 +128,7 @@ struct TraceArgs {
   float* start;
   int32_t start_stride;
   const int32_t* tile_order;
+  int32_t idx_bits;   // kSplit == 2: list entries carry (arrival rank << idx_bits) | index
 };
 
 // ------------------------------------------------------------------------------------
@@ -128,6 +140,7 @@ __global__ __launch_bounds__(256) void k_project(int32_t n, const float* __restr
                                                   const float* __restrict__ scale, FrameCam cam,
                                                   float4* __restrict__ bbox,
                                                   float4* __restrict__ slab_bbox,
+                                                  float* __restrict__ slab_key,
                                                   float* __restrict__ rec) {
   const int g0 = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = g0 < n;
@@ -270,7 +283,15 @@ __global__ __launch_bounds__(256) void k_project(int32_t n, const float* __restr
     bb.z = fmaxf(bb.z, __shfl_xor(bb.z, off));
     bb.w = fmaxf(bb.w, __shfl_xor(bb.w, off));
   }
-  if ((threadIdx.x & (kWave - 1)) == 0 && live) slab_bbox[g0 / kSlab] = bb;
+  // depth key of the slab: summed squared distance of its members from the camera.  k_trace
+  // visits a tile's surviving slabs nearest first, so that far candidates meet full lists.
+  float d2 = (float)(mx * mx + my * my + mz * mz);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) d2 += __shfl_xor(d2, off);
+  if ((threadIdx.x & (kWave - 1)) == 0 && live) {
+    slab_bbox[g0 / kSlab] = bb;
+    slab_key[g0 / kSlab] = d2;
+  }
 }
 
 // Union bounds of kSuper consecutive slabs (big scenes only; see kSuper).
@@ -298,8 +319,9 @@ __global__ __launch_bounds__(256) void k_super_bbox(int32_t nslabs, const float4
 struct Rgb { float r, g, b; };
 // Per-lane list of the RTGS_MAX_DEPTH smallest entry distances: three register arrays (t1 bits,
 // Gaussian index, exponent), sorted ascending, empty slots = +inf.  Keys are the t1 bits alone
-// (t1 > 0, so unsigned order == float order); equal t1 keep their arrival order, which k_trace
-// makes deterministic (stream order).
+// (t1 > 0, so unsigned order == float order); exactly equal t1 (a few dozen pixels per frame)
+// keep their ARRIVAL order, and k_trace makes that order a function of the tile alone (slabs
+// nearest first, lanes in index order): the same in every instantiation and for every sharding.
 //
 // Insertion, chain-free form (default): the new key is compared with all 16 ORIGINAL slots at
 // once (independent compares; the results are monotone because the list is sorted), then every
@@ -324,32 +346,6 @@ __device__ __forceinline__ void list_insert_par(unsigned (&kt)[kK], unsigned (&k
   kt[0] = lt[0] ? tn : kt[0];
   ki[0] = lt[0] ? in : ki[0];
   kw[0] = lt[0] ? wn : kw[0];
-}
-
-// Alternative (RTGS_INSERT=1): serial bubble with the hardware's conditional swap: v_cmpx narrows
-// EXEC to the lanes whose carried key is smaller, three v_swap_b32 exchange the fields there,
-// EXEC is restored.  Fewest instructions, but every level waits for the previous one.
-#define RTGS_SWAP_LEVEL(k)                                                                 \
-  asm volatile(                                                                            \
-      "v_cmpx_lt_u32_e32 vcc, %0, %3\n\t"                                                   \
-      "s_cbranch_execz .Lskip%=\n\t"                                                        \
-      "v_swap_b32 %0, %3\n\t"                                                               \
-      "v_swap_b32 %1, %4\n\t"                                                               \
-      "v_swap_b32 %2, %5\n"                                                                 \
-      ".Lskip%=:\n\t"                                                                       \
-      "s_mov_b64 exec, %6"                                                                 \
-      : "+v"(tn), "+v"(in), "+v"(wn), "+v"(kt[k]), "+v"(ki[k]), "+v"(kw[k])                \
-      : "s"(ex)                                                                            \
-      : "vcc")
-
-__device__ __forceinline__ void list_insert_swap(unsigned (&kt)[RTGS_MAX_DEPTH], unsigned (&ki)[RTGS_MAX_DEPTH],
-                                                 float (&kw)[RTGS_MAX_DEPTH], unsigned tn, unsigned in,
-                                                 float wn) {
-  const unsigned long long ex = __builtin_amdgcn_read_exec();
-  RTGS_SWAP_LEVEL(0); RTGS_SWAP_LEVEL(1); RTGS_SWAP_LEVEL(2); RTGS_SWAP_LEVEL(3);
-  RTGS_SWAP_LEVEL(4); RTGS_SWAP_LEVEL(5); RTGS_SWAP_LEVEL(6); RTGS_SWAP_LEVEL(7);
-  RTGS_SWAP_LEVEL(8); RTGS_SWAP_LEVEL(9); RTGS_SWAP_LEVEL(10); RTGS_SWAP_LEVEL(11);
-  RTGS_SWAP_LEVEL(12); RTGS_SWAP_LEVEL(13); RTGS_SWAP_LEVEL(14); RTGS_SWAP_LEVEL(15);
 }
 
 // gaussian.py:149-163, including the y_33 quirk (5 z^2 - 3 z).
@@ -383,7 +379,10 @@ __device__ __forceinline__ void sh_basis(float x, float y, float z, float (&Y)[R
 // merges (bitonic, ordered by (t1, index) = arrival order) and composites.  Same pixels bit for
 // bit as kSplit = 1.
 template <bool kHasSh, bool kBig, int kK, int kSplit>
-__global__ __launch_bounds__(kTraceBlock * kSplit, kHasSh ? RTGS_WAVES_PER_SIMD_SH : RTGS_WAVES_PER_SIMD) void k_trace(const TraceArgs a,
+__global__ __launch_bounds__(kTraceBlock * kSplit,
+                             kHasSh ? RTGS_WAVES_PER_SIMD_SH
+                                    : (!kBig && kSplit == 1 && kK == RTGS_MAX_DEPTH ? RTGS_WAVES_PER_SIMD_MAIN
+                                                                                    : RTGS_WAVES_PER_SIMD)) void k_trace(const TraceArgs a,
                                                           const float4* __restrict__ bbox,
                                                           const float4* __restrict__ slab_bbox,
                                                           const float4* __restrict__ super_bbox,
@@ -404,6 +403,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit, kHasSh ? RTGS_WAVES_PER_SIMD_
   float4* const s_bb = s_pool;
   int* const s_idx = reinterpret_cast<int*>(s_pool + kListCap);
   __shared__ int s_slab[kSlabCap];
+  __shared__ float s_skey[kSortMax];     // depth keys of the first kSortMax listed slabs
   __shared__ int s_wcnt[2][kWaves];
   __shared__ int s_cnt[kBatch];
   constexpr int kSuperStep = kSlabIters * kBlock;   // slab groups scanned per outer step
@@ -460,6 +460,8 @@ __global__ __launch_bounds__(kTraceBlock * kSplit, kHasSh ? RTGS_WAVES_PER_SIMD_
 
   const unsigned long long lane_lt = (1ull << lane) - 1ull;
   const int nslabs = (a.n + kSlab - 1) / kSlab;
+  // depth keys live behind the slab and group bounds (see slab_key_of)
+  const float* const slab_key = reinterpret_cast<const float*>(slab_bbox + nslabs + (nslabs + kSuper - 1) / kSuper);
 #if RTGS_STAMPS
   unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
   int c_iter = 0, c_hit = 0, c_ins = 0;
@@ -512,6 +514,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit, kHasSh ? RTGS_WAVES_PER_SIMD_
     // without atomics: every wave publishes its count, one barrier later every thread derives
     // the same offsets (s_wcnt is double-buffered by step parity).
     float4 sb[kSlabIters];
+    float sk[kSlabIters];
     int slid[kSlabIters];
 #pragma unroll
     for (int it = 0; it < kSlabIters; ++it) {
@@ -520,7 +523,8 @@ __global__ __launch_bounds__(kTraceBlock * kSplit, kHasSh ? RTGS_WAVES_PER_SIMD_
       if constexpr (kBig) sl = item < nitems ? s_super[item / kSuper] * kSuper + (item % kSuper) : nslabs;
       slid[it] = sl;
       sb[it] = make_float4(kInf, kInf, -kInf, -kInf);
-      if (sl < nslabs) sb[it] = slab_bbox[sl];
+      sk[it] = 0.f;
+      if (sl < nslabs) { sb[it] = slab_bbox[sl]; sk[it] = slab_key[sl]; }
     }
     unsigned long long keep_m[kSlabIters];
     int wcnt = 0;
@@ -541,13 +545,33 @@ __global__ __launch_bounds__(kTraceBlock * kSplit, kHasSh ? RTGS_WAVES_PER_SIMD_
     }
 #pragma unroll
     for (int it = 0; it < kSlabIters; ++it) {
-      if ((keep_m[it] >> lane) & 1ull)
-        s_slab[off + __popcll(keep_m[it] & lane_lt)] = slid[it];
+      if ((keep_m[it] >> lane) & 1ull) {
+        const int at = off + __popcll(keep_m[it] & lane_lt);
+        s_slab[at] = slid[it];
+        if (at < kSortMax) s_skey[at] = sk[it];
+      }
       off += __popcll(keep_m[it]);
     }
     const bool last = last_outer && sbase + kSlabStep >= nitems;
     if (scnt + kSlabStep <= kSlabCap && !last) continue;
     __syncthreads();  // the slab list is complete
+    if (kSortMax > 0 && scnt > 1 && scnt <= kSortMax) {
+      // nearest slabs first: rank by (key, list position), one listed slab per thread.  (One wave
+      // exchanging the keys by v_readlane instead of LDS, and skipping lists shorter than 8 or 16:
+      // all slower, 0.275-0.281 vs 0.270 ms on c3.)
+      int my_slab = 0, rank = 0;
+      if (tid < scnt) {
+        my_slab = s_slab[tid];
+        const float my_key = s_skey[tid];
+        for (int j = 0; j < scnt; ++j) {
+          const float kj = s_skey[j];
+          rank += (kj < my_key || (kj == my_key && j < tid)) ? 1 : 0;
+        }
+      }
+      __syncthreads();
+      if (tid < scnt) s_slab[rank] = my_slab;
+      __syncthreads();
+    }
 #if RTGS_STAMPS
     if (st[1] == 0) st[1] = __builtin_amdgcn_s_memtime();
 #endif
@@ -611,6 +635,8 @@ __global__ __launch_bounds__(kTraceBlock * kSplit, kHasSh ? RTGS_WAVES_PER_SIMD_
           if (slot < cnt) { g = s_idx[slot]; wb = s_bb[slot]; }
           const bool pass = wb.x <= wXhi && wb.z >= wXlo && wb.y <= wYhi && wb.w >= wYlo;
           unsigned long long m = __ballot(pass);
+          [[maybe_unused]] const unsigned long long m_all = m;
+          [[maybe_unused]] const int turn0 = turn;
           if constexpr (kSplit == 2) {
             // keep every other candidate: prefix parity of the mask marks the 1st, 3rd, ... set
             // bit; `turn` carries the parity over from the previous chunks
@@ -682,11 +708,15 @@ __global__ __launch_bounds__(kTraceBlock * kSplit, kHasSh ? RTGS_WAVES_PER_SIMD_
 #endif
 #if RTGS_ABLATE == 1
               asm volatile("" ::"v"(kn), "v"(wn));
-#elif RTGS_INSERT == 3
-              list_insert_par(key, kidx, wexp, kn, (unsigned)gi, wn);
 #else
-              if constexpr (kK == RTGS_MAX_DEPTH) list_insert_swap(key, kidx, wexp, kn, (unsigned)gi, wn);
-              else list_insert_par(key, kidx, wexp, kn, (unsigned)gi, wn);
+              unsigned entry = (unsigned)gi;
+              if constexpr (kSplit == 2) {
+                // arrival rank of this candidate in the tile's stream, above the index bits: the
+                // merge then orders equal t1 exactly as the one-wave form's arrival order does
+                const unsigned rank = (unsigned)(turn0 + __popcll(m_all & ((1ull << b) - 1ull)));
+                entry |= rank << a.idx_bits;
+              }
+              list_insert_par(key, kidx, wexp, kn, entry, wn);
 #endif
 #if RTGS_STAMPS
               t_ins += __builtin_amdgcn_s_memtime() - ti0;
@@ -703,7 +733,9 @@ __global__ __launch_bounds__(kTraceBlock * kSplit, kHasSh ? RTGS_WAVES_PER_SIMD_
 
   if constexpr (kSplit == 2) {
     // ---- hand the helper wave's list over and merge: min(A[i], B[K-1-i]) is the bitonic
-    // sequence of the K smallest of both; log2(K) half-cleaners sort it.  Order = (t1, index).
+    // sequence of the K smallest of both; log2(K) half-cleaners sort it.  Order = (t1, arrival
+    // rank), the rank riding above the index bits of the entries (exact while a tile's stream has
+    // fewer than 2^(32 - idx_bits) candidates; beyond that only the order of exact ties is lost).
     unsigned* const mp = reinterpret_cast<unsigned*>(s_pool) + sub * (3 * kK * kWave) + lane;
     if (role == 1) {
 #pragma unroll
@@ -761,6 +793,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit, kHasSh ? RTGS_WAVES_PER_SIMD_
     const float in = 1.0f / sqrtf(wx * wx + wy * wy + wz * wz);  // gaussian.py:200
     sh_basis(wx * in, wy * in, wz * in, Ysh);
   }
+  [[maybe_unused]] const unsigned idx_mask = (1u << a.idx_bits) - 1u;
   int nhit = 0;
   float last_t = 0.f;
   unsigned prev_tbits = 0u;
@@ -774,7 +807,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit, kHasSh ? RTGS_WAVES_PER_SIMD_
     for (int j = 0; j < kGroup; ++j) {
       const int k = k0 + j;
       const unsigned tb = key[k];
-      const unsigned gi = kidx[k];
+      const unsigned gi = kSplit == 2 ? (kidx[k] & idx_mask) : kidx[k];
       cog[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (tb < 0x7F800000u) cog[j] = colop[gi];
     }
@@ -783,7 +816,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit, kHasSh ? RTGS_WAVES_PER_SIMD_
       const int k = k0 + j;
       if (k < a.depth && !done) {
         const unsigned tbits = key[k];
-        const unsigned gi = kidx[k];
+        const unsigned gi = kSplit == 2 ? (kidx[k] & idx_mask) : kidx[k];
         // an exact repeat of the previous entry distance is what the reference's strict
         // `t1 > ray.start` drops (scene.py:433 after ray_tracer.py:101)
         const bool valid = tbits < 0x7F800000u && tbits != prev_tbits;
@@ -873,7 +906,8 @@ size_t rtgs_workspace_bytes(int32_t n) {
   if (n <= 0) return 0;
   const size_t nn = ((size_t)n + 63) & ~(size_t)63;
   const size_t nslabs = nn / kSlab, nsuper = (nslabs + kSuper - 1) / kSuper;
-  return nn * sizeof(float4) + nn * kRecFloats * sizeof(float) + (nslabs + nsuper) * sizeof(float4);
+  return nn * sizeof(float4) + nn * kRecFloats * sizeof(float) + (nslabs + nsuper) * sizeof(float4) +
+         ((nslabs + 3) & ~(size_t)3) * sizeof(float);
 }
 
 int32_t rtgs_tile_size(void) { return kTile; }
@@ -887,6 +921,12 @@ int32_t rtgs_num_local_tiles(int32_t width, int32_t height, int32_t tile_first, 
   const int32_t total = rtgs_num_tiles(width, height);
   if (tile_step <= 0 || tile_first < 0 || tile_first >= total) return 0;
   return (total - tile_first + tile_step - 1) / tile_step;
+}
+
+// workspace: [bbox nn x float4][records nn x 20 float][slab bounds][group bounds][slab depth keys]
+static float* slab_key_of(float4* slab_bbox, size_t nn) {
+  const size_t nslabs = nn / kSlab, nsuper = (nslabs + kSuper - 1) / kSuper;
+  return reinterpret_cast<float*>(slab_bbox + nslabs + nsuper);
 }
 
 static int validate(const RtgsScene* scene, const RtgsCamera* cam, void* ws, size_t ws_bytes) {
@@ -910,7 +950,7 @@ int rtgs_project(const RtgsScene* scene, const RtgsCamera* cam, void* workspace,
   const int block = 256;
   hipLaunchKernelGGL(k_project, dim3((scene->n + block - 1) / block), dim3(block), 0,
                      static_cast<hipStream_t>(stream), scene->n, scene->position, scene->rotation,
-                     scene->scale, fc, bbox, slab_bbox, rec);
+                     scene->scale, fc, bbox, slab_bbox, slab_key_of(slab_bbox, nn), rec);
   const int nslabs = (int)(nn / kSlab);
   if (nslabs > kBigSceneSlabs) {
     const int nsuper = (nslabs + kSuper - 1) / kSuper;
@@ -965,6 +1005,8 @@ static int trace_impl(const RtgsScene* scene, const RtgsCamera* cam, const RtgsT
   a.start = ray_start;
   a.start_stride = ray_start ? ray_start_stride : 1;
   a.tile_order = params->tile_order;
+  a.idx_bits = 1;
+  while (a.idx_bits < 31 && (1u << a.idx_bits) < (uint32_t)scene->n) ++a.idx_bits;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool big = (scene->n + kSlab - 1) / kSlab > kBigSceneSlabs;
   const float* sh = scene->sh;

@@ -335,6 +335,17 @@ def test_c3_full_size_sharded_equals_whole(c3):
     for r in range(8):
         tracer.trace(depth, tile_first=r, tile_step=8)
     assert torch.equal(tracer.sample_buf, whole)
+    # the same shards in the two-waves-per-tile form, and 16 of them in whatever form the library
+    # picks (510 tiles: two waves): exact t1 ties (a few dozen pixels at this size) must resolve
+    # the same way in every form
+    tracer.clear_sample()
+    for r in range(8):
+        tracer.trace(depth, tile_first=r, tile_step=8, flags=nat.TRACE_SPLIT_ON)
+    assert torch.equal(tracer.sample_buf, whole)
+    tracer.clear_sample()
+    for r in range(16):
+        tracer.trace(depth, tile_first=r, tile_step=16)
+    assert torch.equal(tracer.sample_buf, whole)
 
 
 def test_c3_full_size_sanity(c3):
