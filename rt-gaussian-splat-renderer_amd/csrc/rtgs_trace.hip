@@ -12,10 +12,11 @@
 //     gaussian.py:215-219 is factored per Gaussian.  With E = (X, Y, -1), X/Y the pixel-centre
 //     offsets from the image centre, delta/4 = E^T Q E is a conic in the image plane, and A and
 //     b = B/2 are a quadratic and a linear form in (X, Y).  All three are stored as their
-//     (exact) Taylor polynomials about an expansion point c on the half-integer pixel grid --
-//     the conic's centre clamped to the screen -- so that the fp32 per-ray evaluation works
-//     with small offsets (x, y) = (X, Y) - c and never forms the literal b^2 - A*C, which
-//     loses ~1e-3 relative for a 0.01-unit Gaussian 3 units away.  For an ellipsoid in front of
+//     (exact) Taylor polynomials about an expansion point c -- the on-screen point where delta
+//     is largest, rounded to fp32 -- so that the fp32 per-ray evaluation works with small
+//     offsets (x, y) = (X, Y) - c and never forms the literal b^2 - A*C, which loses ~1e-3
+//     relative for a 0.01-unit Gaussian 3 units away; the quadratic part of delta/4 of an
+//     ellipse is a sum of squares (LDL^T), so sub-pixel needles do not cancel either.  For an ellipsoid in front of
 //     the camera the conic is an ellipse and yields a screen bounding box; Gaussians that
 //     contain the camera or lie behind it are culled here (they can never satisfy t1 > 0);
 //     ellipsoids crossing the camera plane keep no bound and are decided per pixel by b < 0.
@@ -67,6 +68,9 @@ namespace {
 #define RTGS_FAST_DIV 1   // v_rcp_f32 / v_sqrt_f32 (1 ulp) instead of IEEE division / sqrt
 #endif
 
+#ifndef RTGS_SLAB_ITERS
+#define RTGS_SLAB_ITERS 2
+#endif
 constexpr int kSlab = 64;                                 // Gaussians per slab = one wave
 // Batch sizes of the scan / expansion / colour-gather stages.  Measured optimum depends on the
 // number of slabs: c3 (1.6 k slabs) 2/2/4 -> 0.293 ms vs 0.344 with 4/4/8; c5 (15.6 k slabs, SH)
@@ -76,7 +80,7 @@ template <bool kBig, int kSplit = 1>
 struct Tune {
   static constexpr int kWaves = kWavesPerTile * kSplit;     // waves per workgroup
   static constexpr int kBlock = kWaves * kWave;             // threads per workgroup
-  static constexpr int kSlabIters = (kBig ? 4 : 2) / kSplit;  // slab bounds in flight per thread
+  static constexpr int kSlabIters = (kBig ? 4 : RTGS_SLAB_ITERS) / kSplit;  // slab bounds in flight per thread
   static constexpr int kSlabStep = kSlabIters * kBlock;     // slabs scanned per barrier
   static constexpr int kSlabCap = 2048;                      // LDS list of surviving slabs
   static constexpr int kSlabsPerWave = kBig ? 4 : 2;         // slabs one wave expands per batch
@@ -246,8 +250,12 @@ __global__ __launch_bounds__(256) void k_project(int32_t n, const float* __restr
       }
     }
     if (keep && C < inf) {
-      cx = rint(2.0 * cx) * 0.5;
-      cy = rint(2.0 * cy) * 0.5;
+      // the expansion point as the kernel will see it: rounded to fp32, NOT to the pixel grid -- a
+      // needle a hundredth of a pixel wide is tens of its widths away from the nearest half-
+      // integer, and expanding there brings back the cancellation (tools/fuzz_needles.py seed
+      // 9065: delta/4 = -2.2e9 + 4.4e9 - 2.2e9).  x = X - cx then rounds once, to 2^-24 relative.
+      cx = (double)(float)cx;
+      cy = (double)(float)cy;
       // E_c = (cx, cy, -1)
       const double q0 = Q00 * cx + Q01 * cy - Q02, q1 = Q01 * cx + Q11 * cy - Q12,
                    q2 = Q02 * cx + Q12 * cy - Q22;
@@ -257,7 +265,19 @@ __global__ __launch_bounds__(256) void k_project(int32_t n, const float* __restr
       r[0] = (float)cx;              r[1] = (float)cy;
       r[2] = (float)(cx * q0 + cy * q1 - q2);      // delta/4 at the expansion point
       r[3] = (float)(2.0 * q0);      r[4] = (float)(2.0 * q1);   // its gradient
-      r[5] = (float)(-Q00);          r[6] = (float)(-2.0 * Q01); r[7] = (float)(-Q11);
+      // quadratic part x^T P x, P = -Q(2x2).  For an ellipse (P positive definite) in the LDL^T
+      // form d1 (x + l y)^2 + d2 y^2: a SUM OF SQUARES, so a needle a fraction of a pixel wide does
+      // not lose its exponent to cancellation between p00 x^2, 2 p01 x y and p11 y^2 (a 200:1
+      // needle 0.06 px wide, 20 px from its expansion point: 2e-3 relative in delta with the plain
+      // polynomial, 2e-5 this way; tools/fuzz_needles.py seed 9021).  Other conics keep the
+      // polynomial: d1 = p00, l = 0, d2 = p11 and the cross term 2 p01 in r[18].
+      if (Q00 < 0.0 && det > 0.0) {
+        r[5] = (float)(-Q00);        r[6] = (float)(Q01 / Q00);   r[7] = (float)(det / -Q00);
+        r[18] = 0.f;
+      } else {
+        r[5] = (float)(-Q00);        r[6] = 0.f;                  r[7] = (float)(-Q11);
+        r[18] = (float)(-2.0 * Q01);
+      }
       r[8] = (float)(cx * e0 + cy * e1 - e2);      // A at the expansion point
       r[9] = (float)(2.0 * e0);      r[10] = (float)(2.0 * e1);
       r[11] = (float)Mc[0][0];       r[12] = (float)(2.0 * Mc[0][1]); r[13] = (float)Mc[1][1];
@@ -286,6 +306,7 @@ __global__ __launch_bounds__(256) void k_project(int32_t n, const float* __restr
   // depth key of the slab: summed squared distance of its members from the camera.  k_trace
   // visits a tile's surviving slabs nearest first, so that far candidates meet full lists.
   float d2 = (float)(mx * mx + my * my + mz * mz);
+  d2 = d2 == d2 ? d2 : kInf;   // a NaN key would give two slabs the same rank in k_trace's sort
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) d2 += __shfl_xor(d2, off);
   if ((threadIdx.x & (kWave - 1)) == 0 && live) {
@@ -668,10 +689,14 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
                          "s"(q1.w), "s"(q2.x), "s"(q2.y), "s"(q2.z), "s"(q2.w), "s"(q3.x), "s"(q3.y),
                          "s"(q3.z), "s"(q3.w), "s"(q4.x), "s"(q4.y));
 #endif
-            // delta/4 = e_c + g.(x,y) - (x,y) P (x,y)^T about the record's expansion point
+            // delta/4 = e_c + g.(x,y) - d1 (x + l y)^2 - d2 y^2 - cr x y about the record's
+            // expansion point (k_project: sum-of-squares form for ellipses, cr = 0)
             const float x = X - q0.x;
             const float y = Y - q0.y;
-            const float e = q0.z - ((q1.y * x + q1.z * y - q0.w) * x + (q1.w * y - q1.x) * y);
+            const float u = fmaf(q1.z, y, x);
+            float e = fmaf(x, fmaf(-q4.z, y, q0.w), q0.z);
+            e = fmaf(y, fmaf(-q1.w, y, q1.x), e);
+            e = fmaf(-(q1.y * u), u, e);
             bool hit = e > 0.f && in_img;
 #if RTGS_ABLATE == 2
             asm volatile("" ::"v"(e));
@@ -681,8 +706,11 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
 #if RTGS_STAMPS
             ++c_hit;
 #endif
-            const float A = q2.x + q2.y * x + q2.z * y + (q2.w * x + q3.x * y) * x + (q3.y * y) * y;
-            const float bq = q3.z + q3.w * x + q4.x * y;
+            // explicit fma chains: every instantiation (K = 1 / 16, one or two waves, SH or not)
+            // must round t1 and the exponent identically, or two hits one ulp apart in t1 could
+            // composite in a different order in a progressive sample() than in a one-pass trace
+            const float A = fmaf(y, fmaf(q3.y, y, q2.z), fmaf(x, fmaf(q3.x, y, fmaf(q2.w, x, q2.y)), q2.x));
+            const float bq = fmaf(q4.x, y, fmaf(q3.w, x, q3.z));
             hit = hit && bq < 0.f;   // the cone half in front of the camera
             // smaller root of A t^2 + 2 b t + C (gaussian.py:224) in its cancellation-free form
             // t1 = C / (sqrt(delta/4) - b): C > 0 and b < 0, so nothing is subtracted.

@@ -99,3 +99,21 @@ def fuzz_case(seed):
     world = int(rng.choice([1, 1, 2, 5, 8]))
     mode = int(rng.integers(0, 4))
     return arrays, cam, depth, world, mode
+
+
+def needle_case(seed):
+    """tools/fuzz_needles.py generator: capture-like Gaussians, log-uniform scales, anisotropy up
+    to ~300:1 (sub-pixel-wide needles), random camera.  Returns (arrays, cam)."""
+    rng = np.random.default_rng(seed)
+    w, h = int(rng.integers(64, 200)), int(rng.integers(48, 160))
+    n = int(rng.choice([500, 3000, 12000]))
+    arrays = synthetic.make_scene(n, w / h, seed)
+    lo, hi = np.log(1e-3), np.log(1e-1)
+    base = np.exp(rng.uniform(lo, hi, (n, 1)))
+    aniso = np.exp(rng.uniform(0, np.log(rng.choice([10.0, 100.0, 300.0])), (n, 3)))
+    arrays["scale"] = (base * aniso / aniso.max(axis=1, keepdims=True) * rng.choice([1.0, 3.0])).astype(np.float32)
+    cam = synthetic.bench_camera(w, h)
+    cam["position"] = f32_tuple(rng.normal(size=3) * 0.3 + np.array([0, 0, rng.choice([1.5, 3.0, 6.0])]))
+    cam["rotation"] = quat_axis_angle(rng.normal(size=3), rng.uniform(0, 0.4))
+    cam["fx"] = cam["fy"] = float(np.float32(h * rng.uniform(0.8, 2.5)))
+    return arrays, cam
