@@ -9,6 +9,7 @@ from oracle import c_oracle
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 worst, bad, frag_tot, pix_tot = 0.0, [], 0, 0
+top = []   # (error, seed, ...) of the worst few cases
 t0 = time.time()
 for seed in range(7000, 7000 + n_cases):
     arrays, cam, depth, world, mode = scenes.fuzz_case(seed)
@@ -44,6 +45,8 @@ for seed in range(7000, 7000 + n_cases):
     frag_tot += int((~solid).sum()); pix_tot += err.size
     e = float(err[solid].max()) if solid.any() else 0.0
     worst = max(worst, e)
+    top = sorted(top + [(e, seed, w, h, n, depth, world, mode, float(arrays['scale'].max()))], reverse=True)[:5]
     if e > 1e-4 or not np.isfinite(got).all():
         bad.append((seed, e, w, h, n, depth, world, float(arrays["scale"].max())))
 print(f"{n_cases} cases in {time.time()-t0:.1f}s: worst robust-pixel error {worst:.3e}; fragile {frag_tot}/{pix_tot} = {frag_tot/max(pix_tot,1):.3%}; failures: {bad}")
+print("worst cases (err, seed, w, h, n, depth, world, mode, max scale):", [tuple(round(v, 7) if isinstance(v, float) else v for v in t) for t in top])
