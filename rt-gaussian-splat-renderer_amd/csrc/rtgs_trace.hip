@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void k_project(int32_t n, const float* __restr
     // checking the centre and the minimiser of each edge).  Every on-screen pixel then has
     // 0 <= terms <= delta(there) <= 3 A, so the fp32 Taylor evaluation never cancels, however
     // far off-screen the centre is; and if even that maximum is <= 0 the Gaussian is invisible.
-    // Other conics (near the camera, well conditioned anyway) expand about the screen centre.
+    // Other conics: see the else branch.
     const double hw = 0.5 * cam.width, hh = 0.5 * cam.height;
     double cx = 0.0, cy = 0.0;
     if (keep && Q00 < 0.0 && det > 0.0) {
@@ -248,6 +248,29 @@ __global__ __launch_bounds__(256) void k_project(int32_t n, const float* __restr
         const double K = Q22 - (Q02 * X0 + Q12 * Y0);
         if (!(best < K)) keep = false;   // delta/4 = K - f <= 0 on the whole screen (NaN: cull)
       }
+    } else if (keep) {
+      // Not an ellipse (the ellipsoid crosses the camera plane): delta has no bounded maximum, so
+      // the expansion starts from the screen centre (offsets bounded by half the screen) -- and,
+      // if the conic has a dominant positive eigenvalue, i.e. it is a needle, slides across the
+      // needle onto its ridge, so that pixels inside the needle see a small perpendicular offset
+      // (tests/scenes.py fuzz seeds 8476 / 8982: 7e-5 without).  Chasing the largest delta over
+      // the screen instead is wrong: it runs away along the open branch (errors up to 1.6e-2).
+      const double P00 = -Q00, P01 = -Q01, P11 = -Q11;
+      const double half_tr = 0.5 * (P00 + P11), rad = sqrt(0.25 * (P00 - P11) * (P00 - P11) + P01 * P01);
+      const double lam = half_tr + rad;          // the larger eigenvalue of P
+      if (lam > 0.0 && lam > 16.0 * fabs(half_tr - rad)) {
+        double nx = P01, ny = lam - P00;         // its eigenvector, from the better-conditioned row
+        if (fabs(lam - P11) > fabs(ny)) { nx = lam - P11; ny = P01; }
+        const double nn = sqrt(nx * nx + ny * ny);
+        if (nn > 0.0 && nn < inf) {
+          nx /= nn; ny /= nn;
+          // delta/4 (c + s n) = f(c) + 2 s n.q - s^2 lam, q = (Q E_c)_{xy}: largest at s = n.q / lam
+          const double q0c = Q00 * cx + Q01 * cy - Q02, q1c = Q01 * cx + Q11 * cy - Q12;
+          const double sstep = (nx * q0c + ny * q1c) / lam;
+          const double tx = cx + sstep * nx, ty = cy + sstep * ny;
+          if (fabs(tx) <= hw && fabs(ty) <= hh) { cx = tx; cy = ty; }
+        }
+      }
     }
     if (keep && C < inf) {
       // the expansion point as the kernel will see it: rounded to fp32, NOT to the pixel grid -- a
@@ -264,25 +287,38 @@ __global__ __launch_bounds__(256) void k_project(int32_t n, const float* __restr
       const double e2 = Mc[2][0] * cx + Mc[2][1] * cy - Mc[2][2];
       r[0] = (float)cx;              r[1] = (float)cy;
       r[2] = (float)(cx * q0 + cy * q1 - q2);      // delta/4 at the expansion point
-      r[3] = (float)(2.0 * q0);      r[4] = (float)(2.0 * q1);   // its gradient
-      // quadratic part x^T P x, P = -Q(2x2).  For an ellipse (P positive definite) in the LDL^T
-      // form d1 (x + l y)^2 + d2 y^2: a SUM OF SQUARES, so a needle a fraction of a pixel wide does
-      // not lose its exponent to cancellation between p00 x^2, 2 p01 x y and p11 y^2 (a 200:1
-      // needle 0.06 px wide, 20 px from its expansion point: 2e-3 relative in delta with the plain
-      // polynomial, 2e-5 this way; tools/fuzz_needles.py seed 9021).  Other conics keep the
+      // quadratic part x^T P x, P = -Q(2x2), in LDL^T form about the larger diagonal entry:
+      // d1 (x' + l y')^2 + d2 y'^2 with (x', y') = (x, y) or, flagged in r[19], (y, x).  For an
+      // ellipse (P positive definite) that is a SUM OF SQUARES, so a needle a fraction of a pixel
+      // wide does not lose its exponent to cancellation between p00 x^2, 2 p01 x y and p11 y^2 (a
+      // 200:1 needle 0.06 px wide, 20 px from its expansion point: 2e-3 relative in delta with the
+      // plain polynomial, 2e-5 this way; tools/fuzz_needles.py seed 9021).  Other conics take it
+      // when the pivot dominates the off-diagonal entry (needles again); otherwise they keep the
       // polynomial: d1 = p00, l = 0, d2 = p11 and the cross term 2 p01 in r[18].
-      if (Q00 < 0.0 && det > 0.0) {
-        r[5] = (float)(-Q00);        r[6] = (float)(Q01 / Q00);   r[7] = (float)(det / -Q00);
-        r[18] = 0.f;
-      } else {
-        r[5] = (float)(-Q00);        r[6] = 0.f;                  r[7] = (float)(-Q11);
-        r[18] = (float)(-2.0 * Q01);
+      bool swp = false;
+      {
+        const double P00 = -Q00, P01 = -Q01, P11 = -Q11;
+        const bool ellipse = Q00 < 0.0 && det > 0.0;
+        swp = !ellipse && fabs(P11) > fabs(P00);   // an ellipse is a sum of squares either way
+        const double piv = swp ? P11 : P00;
+        if ((ellipse || fabs(piv) >= fabs(P01)) && fabs(piv) > 0.0 && fabs(piv) < inf) {
+          r[5] = (float)piv;           r[6] = (float)(P01 / piv);   r[7] = (float)(det / piv);
+          r[18] = 0.f;
+        } else {
+          swp = false;
+          r[5] = (float)P00;           r[6] = 0.f;                  r[7] = (float)P11;
+          r[18] = (float)(2.0 * P01);
+        }
       }
+      // with the flag set k_trace exchanges x and y once, so every polynomial is stored in (y, x)
+      r[19] = swp ? 1.f : 0.f;
+      r[3] = (float)(2.0 * (swp ? q1 : q0));       r[4] = (float)(2.0 * (swp ? q0 : q1));   // gradient of delta/4
       r[8] = (float)(cx * e0 + cy * e1 - e2);      // A at the expansion point
-      r[9] = (float)(2.0 * e0);      r[10] = (float)(2.0 * e1);
-      r[11] = (float)Mc[0][0];       r[12] = (float)(2.0 * Mc[0][1]); r[13] = (float)Mc[1][1];
+      r[9] = (float)(2.0 * (swp ? e1 : e0));       r[10] = (float)(2.0 * (swp ? e0 : e1));
+      r[11] = (float)(swp ? Mc[1][1] : Mc[0][0]);  r[12] = (float)(2.0 * Mc[0][1]);
+      r[13] = (float)(swp ? Mc[0][0] : Mc[1][1]);
       r[14] = (float)(v[0] * cx + v[1] * cy - v[2]);  // b = B/2 at the expansion point
-      r[15] = (float)v[0];           r[16] = (float)v[1];
+      r[15] = (float)(swp ? v[1] : v[0]);          r[16] = (float)(swp ? v[0] : v[1]);
       r[17] = (float)C;
     } else {
       bb = make_float4(kInf, kInf, -kInf, -kInf);
@@ -689,10 +725,13 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
                          "s"(q1.w), "s"(q2.x), "s"(q2.y), "s"(q2.z), "s"(q2.w), "s"(q3.x), "s"(q3.y),
                          "s"(q3.z), "s"(q3.w), "s"(q4.x), "s"(q4.y));
 #endif
-            // delta/4 = e_c + g.(x,y) - d1 (x + l y)^2 - d2 y^2 - cr x y about the record's
-            // expansion point (k_project: sum-of-squares form for ellipses, cr = 0)
-            const float x = X - q0.x;
-            const float y = Y - q0.y;
+            // delta/4 = e_c + g.(x',y') - d1 (x' + l y')^2 - d2 y'^2 - cr x y about the record's
+            // expansion point, (x', y') = (x, y) or (y, x) (k_project: LDL^T about the larger pivot)
+            float x = X - q0.x;
+            float y = Y - q0.y;
+            // records of non-elliptic conics pivoted on p11 are stored in (y, x): a real (scalar)
+            // branch around one v_swap_b32, not two selects on every candidate (0.283 vs 0.274 ms)
+            if (__builtin_expect(q4.w != 0.f, 0)) asm volatile("v_swap_b32 %0, %1" : "+v"(x), "+v"(y));
             const float u = fmaf(q1.z, y, x);
             float e = fmaf(x, fmaf(-q4.z, y, q0.w), q0.z);
             e = fmaf(y, fmaf(-q1.w, y, q1.x), e);

@@ -21,7 +21,8 @@ tr.trace(depth); torch.cuda.synchronize()
 got = tr.sample_buf.cpu().numpy().reshape(-1, 3)
 want = c_oracle.render(arrays, cam, depth)
 err = np.abs(got - want["sample"]).max(axis=1); solid = ~want["fragile"]
-bad = np.nonzero((err > 1e-4) & solid)[0]
+thr = float(sys.argv[2]) if len(sys.argv) > 2 else 1e-4
+bad = np.nonzero((err > thr) & solid)[0]
 print("bad robust pixels", bad.size, "of", solid.sum())
 osc = ref.OracleScene(**arrays)
 for p in bad[np.argsort(-err[bad])][:4]:
