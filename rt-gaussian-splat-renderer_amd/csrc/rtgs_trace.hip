@@ -15,25 +15,27 @@
 //     (exact) Taylor polynomials about an expansion point c -- the on-screen point where delta
 //     is largest, rounded to fp32 -- so that the fp32 per-ray evaluation works with small
 //     offsets (x, y) = (X, Y) - c and never forms the literal b^2 - A*C, which loses ~1e-3
-//     relative for a 0.01-unit Gaussian 3 units away; the quadratic part of delta/4 of an
-//     ellipse is a sum of squares (LDL^T), so sub-pixel needles do not cancel either.  For an ellipsoid in front of
-//     the camera the conic is an ellipse and yields a screen bounding box; Gaussians that
+//     relative for a 0.01-unit Gaussian 3 units away; the quadratic part of delta/4 is a sum
+//     of squares (LDL^T), so sub-pixel needles do not cancel either.  For an ellipsoid in front
+//     of the camera the conic is an ellipse and yields a screen bounding box; Gaussians that
 //     contain the camera or lie behind it are culled here (they can never satisfy t1 > 0);
 //     ellipsoids crossing the camera plane keep no bound and are decided per pixel by b < 0.
 //     Gaussians are streamed in SLABS of 64 consecutive records (one wave of k_project); the
-//     wave also reduces the slab's union screen bound.  With the scene stored in Morton order
-//     (rtgs.Scene does that at load) a slab is spatially compact, so its bound is tight.
+//     wave also reduces the slab's union screen bound and a depth key.  With the scene stored in
+//     Morton order (rtgs.Scene does that at load) a slab is spatially compact: its bound is tight.
 //   * k_trace: one workgroup per RTGS_TILE x RTGS_TILE macro-tile, one wave64 per 8x8 pixel
-//     tile, one lane per ray.  The workgroup scans the slab bounds (16 B per 64 Gaussians),
-//     keeps the slabs that touch the macro-tile (deterministic ballot/prefix compaction into
-//     LDS), expands them -- one wave per slab, one lane per Gaussian, 16 B bounds, SoA in HBM --
-//     and compacts the surviving Gaussians into an LDS list.  Each wave then re-tests the
+//     tile (two for small launches, kSplit), one lane per ray.  The workgroup scans the slab
+//     bounds (16 B per 64 Gaussians; in two levels for big scenes), keeps the slabs that touch
+//     the macro-tile (deterministic ballot/prefix compaction into LDS), orders them nearest
+//     first, expands them -- one wave per slab, one lane per Gaussian, 16 B bounds, SoA in HBM
+//     -- and compacts the surviving Gaussians into an LDS list.  Each wave then re-tests the
 //     survivors against its own 8x8 tile (one survivor per lane, ballot) and, for every set
-//     bit, all 64 rays evaluate the exact conic with the record broadcast by v_readlane.  Hits
-//     go into a per-lane sorted register list of the RTGS_MAX_DEPTH nearest (t1, index) -- the
-//     reference's `depth` peels in one pass -- and are composited front to back at the end; a
-//     wave ballot ends the compositing loop early when every lane is below the transmittance
-//     cut-off.  No MFMA: there is no contraction anywhere on this path.
+//     bit, all 64 rays evaluate the exact conic; the record's address is wave-uniform, so it
+//     arrives by scalar loads.  Hits go into a per-lane sorted register list of the
+//     RTGS_MAX_DEPTH nearest (t1, index) -- the reference's `depth` peels in one pass -- and are
+//     composited front to back at the end; a wave ballot ends the compositing loop early when
+//     every lane is below the transmittance cut-off.  No MFMA: there is no contraction anywhere
+//     on this path.
 #include "rtgs_common.hpp"
 
 namespace rtgs {
@@ -43,8 +45,8 @@ namespace {
 // Other things tried and dropped, same scene: record broadcast with v_readlane from a lane-held
 // copy 0.426 ms vs scalar loads 0.377; scalar loads prefetched one candidate ahead 0.406 (SGPR
 // pressure); IEEE division/sqrt +8 %; 32x32 macro-tiles 0.475, 8x8 single-wave workgroups 0.473;
-// 5 or 6 waves/SIMD = 4; a second slab level (1024-Gaussian groups) -12 % at 100 k Gaussians,
-// +3 % at 1 M; XCD-contiguous tile chunks 0.444 (centre-heavy scene: imbalance), row-striped
+// a second slab level (1024-Gaussian groups) -12 % at 100 k Gaussians (it is what Tune<true> uses
+// above 262 k); XCD-contiguous tile chunks 0.444 (centre-heavy scene: imbalance), row-striped
 // XCD map no gain; software-pipelining insertion(k) with the test of k+1 0.329.
 #ifndef RTGS_REC_MODE
 #define RTGS_REC_MODE 1   // 1: scalar record loads where first needed; 3: whole record up front
@@ -115,7 +117,6 @@ constexpr int kSuper = RTGS_SUPER;
 #define RTGS_SORT_MAX 256
 #endif
 constexpr int kSortMax = RTGS_SORT_MAX;
-
 
 struct TraceArgs {
   int32_t n;
