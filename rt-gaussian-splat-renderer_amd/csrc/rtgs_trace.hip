@@ -99,6 +99,9 @@ constexpr int kBigSceneSlabs = RTGS_BIG_SLABS;   // scenes with more slabs than 
 #define RTGS_SPLIT_MAX_TILES 832
 #endif
 constexpr int kSplitMaxTiles = RTGS_SPLIT_MAX_TILES;
+#ifndef RTGS_TWO_LEVEL
+#define RTGS_TWO_LEVEL 0   // 1: small scenes scan slab bounds in two levels too (c3: k_trace 0.260 vs
+#endif                      // 0.261 ms, but + 3 us for the k_super_bbox launch: no gain)
 #ifndef RTGS_SUPER
 #define RTGS_SUPER 16
 #endif
@@ -465,7 +468,8 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   __shared__ int s_wcnt[2][kWaves];
   __shared__ int s_cnt[kBatch];
   constexpr int kSuperStep = kSlabIters * kBlock;   // slab groups scanned per outer step
-  __shared__ int s_super[kBig ? kSuperStep : 1];
+  constexpr bool kTwo = kBig || RTGS_TWO_LEVEL;   // two-level slab scan
+  __shared__ int s_super[kTwo ? kSuperStep : 1];
   __shared__ int s_wcnt2[2][kWaves];
 
   const int tid = threadIdx.x;
@@ -528,11 +532,11 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
 #endif
   int scnt = 0;  // surviving slabs listed so far: identical in every thread
   int turn = 0;  // kSplit == 2: candidates of this 8x8 tile seen so far (wave-uniform)
-  const int nsuper = kBig ? (nslabs + kSuper - 1) / kSuper : 1;
+  const int nsuper = kTwo ? (nslabs + kSuper - 1) / kSuper : 1;
   int par = 0;
   for (int ub = 0, upar = 0; ub < nsuper; ub += kSuperStep, upar ^= 1) {
   int nitems = nslabs;
-  if constexpr (kBig) {
+  if constexpr (kTwo) {
     // ---- level 1: bounds of kSuper-slab groups; survivors in stream order into s_super ----
     float4 gbb[kSlabIters];
 #pragma unroll
@@ -578,7 +582,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
     for (int it = 0; it < kSlabIters; ++it) {
       const int item = sbase + it * kBlock + tid;
       int sl = item;
-      if constexpr (kBig) sl = item < nitems ? s_super[item / kSuper] * kSuper + (item % kSuper) : nslabs;
+      if constexpr (kTwo) sl = item < nitems ? s_super[item / kSuper] * kSuper + (item % kSuper) : nslabs;
       slid[it] = sl;
       sb[it] = make_float4(kInf, kInf, -kInf, -kInf);
       sk[it] = 0.f;
@@ -1020,7 +1024,7 @@ int rtgs_project(const RtgsScene* scene, const RtgsCamera* cam, void* workspace,
                      static_cast<hipStream_t>(stream), scene->n, scene->position, scene->rotation,
                      scene->scale, fc, bbox, slab_bbox, slab_key_of(slab_bbox, nn), rec);
   const int nslabs = (int)(nn / kSlab);
-  if (nslabs > kBigSceneSlabs) {
+  if (nslabs > kBigSceneSlabs || RTGS_TWO_LEVEL) {
     const int nsuper = (nslabs + kSuper - 1) / kSuper;
     hipLaunchKernelGGL(k_super_bbox, dim3((nsuper + block - 1) / block), dim3(block), 0,
                        static_cast<hipStream_t>(stream), nslabs, slab_bbox, slab_bbox + nslabs);
