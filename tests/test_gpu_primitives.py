@@ -240,3 +240,22 @@ def test_cli_renders_headless(tmp_path):
     out2 = tmp_path / "syn.png"
     assert main(["--synthetic", "2000", "-r", "128,72", "--radius", "3", "--one-pass", "--out", str(out2)]) == 0
     assert out2.read_bytes().startswith(b"\x89PNG")
+
+
+def test_headless_cli_renders_a_ply_and_a_synthetic_scene(tmp_path, capsys):
+    # the reference's `uv run start -o scene.ply -r W,H -f fov -s samples -d depth --scale s`
+    # (__main__.py:34-142) without the ti.GUI window: same flags, image written instead of shown.
+    # Called in-process: a GPU-initialised process must not exec another program here.
+    from rtgs.__main__ import main
+    ply = os.path.join(U.GOLDEN, "test.ply")
+    a, b = str(tmp_path / "peel.ppm"), str(tmp_path / "onepass.ppm")
+    common = ["-o", ply, "-r", "96,64", "-f", "60", "-d", "8", "--scale", "8", "--radius", "3"]
+    assert main(common + ["-s", "1", "--out", a]) == 0                 # the viewer loop: one peel per call
+    assert main(common + ["-s", "1", "--out", b, "--one-pass"]) == 0
+    img_a, img_b = open(a, "rb").read(), open(b, "rb").read()
+    assert img_a[:2] == b"P6" and len(img_a) == len(img_b) > 96 * 64 * 3
+    assert img_a == img_b and any(v != 0 for v in img_a[-96 * 64 * 3:])   # same picture, not black
+    c = str(tmp_path / "syn.png")
+    assert main(["--synthetic", "2000", "-r", "64,48", "--radius", "3", "--out", c, "--one-pass", "-s", "2"]) == 0
+    assert open(c, "rb").read()[:8] == b"\x89PNG\r\n\x1a\n"
+    assert "Gaussians" in capsys.readouterr().out
