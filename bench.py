@@ -162,6 +162,19 @@ def main():
     torch.cuda.synchronize()
     project_ms = ev0.elapsed_time(ev1) / reps
 
+    # SURVEY 8(d) secondary figures: per-frame HIP-event times (median of 30 frames, first launch
+    # to framebuffer complete) and closest-hit queries/s = depth x rays/s
+    frame_ms_median = None
+    if world == 1:
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(30)]
+        for a_, b_ in evs:
+            a_.record()
+            renderer.render_frame()
+            b_.record()
+        renderer.finish()
+        torch.cuda.synchronize()
+        frame_ms_median = sorted(a_.elapsed_time(b_) for a_, b_ in evs)[len(evs) // 2]
+
     verified = None
     if world > 1 and rank == 0:
         # the gathered, de-interleaved frame must equal a single-rank render of the same frame
@@ -198,6 +211,8 @@ def main():
                                  "k_trace time; screen-space culling skips most of that stream, "
                                  "so frac > 1 is possible; physical HBM bytes: profiles/"},
         }
+        line["secondary"] = {"closest_hit_queries_per_s": mrays * 1e6 * cfg.depth,
+                             "frame_ms_median_hip_events": frame_ms_median}
         if verified is not None:
             line["verified"] = verified
         if world == 1 and not args.no_cpu_baseline:
