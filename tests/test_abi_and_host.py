@@ -163,3 +163,23 @@ def test_cli_orbit_pose_and_image_writer(tmp_path):
     write_image(str(tmp_path / "a.png"), disp)
     png = (tmp_path / "a.png").read_bytes()
     assert png.startswith(b"\x89PNG\r\n\x1a\n") and b"IEND" in png
+
+
+def test_driver_entry_points_exist_and_fail_loudly_without_a_gpu():
+    # the round driver imports __graft_entry__ (build / smoke) and runs bench.py; without a HIP
+    # device both must say so instead of falling back to anything
+    import importlib.util
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("graft_entry", os.path.join(root, "__graft_entry__.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert callable(mod.build) and callable(mod.smoke)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True)
+    assert out.returncode == 0 and "--gpus" in out.stdout and "--steps" in out.stdout and "--warmup" in out.stdout
+    import torch
+    if not torch.cuda.is_available():
+        run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"],
+                             capture_output=True, text=True)
+        assert run.returncode != 0 and "HIP device" in (run.stderr + run.stdout)
