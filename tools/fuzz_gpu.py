@@ -45,6 +45,8 @@ for seed in range(7000, 7000 + n_cases):
     frag_tot += int((~solid).sum()); pix_tot += err.size
     e = float(err[solid].max()) if solid.any() else 0.0
     worst = max(worst, e)
+    if (seed - 7000) % 250 == 249:   # a long run must keep talking
+        print(f"  {seed - 6999} cases, worst so far {worst:.3e}, failures {len(bad)}", flush=True)
     top = sorted(top + [(e, seed, w, h, n, depth, world, mode, float(arrays['scale'].max()))], reverse=True)[:5]
     if e > 1e-4 or not np.isfinite(got).all():
         bad.append((seed, e, w, h, n, depth, world, float(arrays["scale"].max())))

@@ -20,5 +20,7 @@ for seed in range(first, first + n_cases):
     err = np.abs(got - want["sample"]).max(axis=1); solid = ~want["fragile"]
     e = float(err[solid].max()) if solid.any() else 0.0
     worst = max(worst, e); hist.append(e)
+    if len(hist) % 250 == 0:
+        print(f"  {len(hist)} cases, worst so far {worst:.3e}, failures {len(bad)}", flush=True)
     if e > 1e-4: bad.append((seed, e, n, float((arrays["scale"].max(1) / arrays["scale"].min(1)).max()), float(want["hits"].mean()), float(1 - solid.mean())))
 print(f"{n_cases} needle cases: worst {worst:.3e}; median of per-case max {np.median(hist):.2e}; failures {bad}")
