@@ -42,7 +42,26 @@ def save(name, pixels, r):
           f"{int(r['fragile'].sum())}, {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def c_render_checked(name, extra, n_check):
+    """C oracle on the centre crop + `extra` seeded random pixels of config `name`, cross-checked
+    against the NumPy oracle on `n_check` of them before being written."""
+    arrays, cam, depth = scenes.config_case(name)
+    pix = scenes.crop_pixels(cam["width"], cam["height"], extra=extra)
+    r = c_oracle.render(arrays, cam, depth, pix)
+    sub = np.arange(0, pix.shape[0], pix.shape[0] // n_check)[:n_check]
+    chk = numpy_render(arrays, cam, depth, pix[sub])
+    assert np.abs(chk["sample"] - r["sample"][sub]).max() < 1e-9
+    assert (chk["hits"] == r["hits"][sub]).all()
+    save(name + "_crop", pix, r)
+
+
 def main():
+    only = set(sys.argv[1:])
+    if only == {"c5"}:
+        # c5: 1 M Gaussians + degree-3 SH at 3840x2160 (gaussian.py:140-181, 183-201): 64x36 centre
+        # crop + 1024 random pixels, C oracle (~1 min on 8 cores), 64 pixels cross-checked
+        c_render_checked("c5", 1024, 64)
+        return
     # c1: the full 128x128 image (SURVEY.md 8c: config-1 full image + per-pixel hit counts)
     arrays, cam, depth = scenes.config_case("c1")
     pix = scenes.all_pixels(cam["width"], cam["height"])
@@ -52,14 +71,8 @@ def main():
     pix = scenes.crop_pixels(cam["width"], cam["height"])
     save("c2_crop", pix, numpy_render(arrays, cam, depth, pix))
     # c3: same pixel pattern, C oracle, cross-checked against NumPy on a subset
-    arrays, cam, depth = scenes.config_case("c3")
-    pix = scenes.crop_pixels(cam["width"], cam["height"], extra=4096)
-    r = c_oracle.render(arrays, cam, depth, pix)
-    sub = np.arange(0, pix.shape[0], pix.shape[0] // 192)[:192]
-    chk = numpy_render(arrays, cam, depth, pix[sub])
-    assert np.abs(chk["sample"] - r["sample"][sub]).max() < 1e-9
-    assert (chk["hits"] == r["hits"][sub]).all()
-    save("c3_crop", pix, r)
+    c_render_checked("c3", 4096, 192)
+    c_render_checked("c5", 1024, 64)
     # special cases, full frames
     for name, fn in scenes.CASES.items():
         arrays, cam, depth = fn()

@@ -25,7 +25,7 @@ def render_full(name):
     return tracer, cam, depth
 
 
-@pytest.mark.parametrize("name", ["c1_full", "c2_crop", "c3_crop", "oblique_full", "inside_full",
+@pytest.mark.parametrize("name", ["c1_full", "c2_crop", "c3_crop", "c5_crop", "oblique_full", "inside_full",
                                   "sh_full", "shallow_full"])
 def test_golden_parity(name):
     g = U.golden(name)
@@ -352,6 +352,58 @@ def test_c3_full_size_sanity(c3):
     _, _, _, whole = c3
     assert torch.isfinite(whole).all()
     assert 0.2 < float(whole.mean()) < 0.6 and float(whole.max()) <= 1.0 + 1e-5 and float(whole.min()) >= 0.0
+
+
+# ---- the same at BASELINE.json's largest config (c5: 1 M Gaussians + degree-3 SH, 3840x2160):
+# the k_trace<sh, big> instantiation with the two-level slab scan and the 180-B SH gathers
+# (gaussian.py:140-181, 183-201); pixel parity of the same frame is test_golden_parity[c5_crop] ----
+
+@pytest.fixture(scope="module")
+def c5():
+    arrays, cam, depth = U.case("c5")
+    scene, camera, tracer = U.build(arrays, cam)
+    tracer.trace(depth)
+    torch.cuda.synchronize()
+    return scene, camera, tracer, depth, tracer.sample_buf.clone()
+
+
+def test_c5_full_size_sharded_equals_whole_and_is_deterministic(c5):
+    scene, camera, tracer, depth, whole = c5
+    tracer.trace(depth)                    # outputs are overwritten: same bits on a second run
+    assert torch.equal(tracer.sample_buf, whole)
+    tracer.clear_sample()
+    for r in range(8):                     # config c5 as BASELINE names it: 8 tile-interleaved shards
+        tracer.trace(depth, tile_first=r, tile_step=8)
+    assert torch.equal(tracer.sample_buf, whole)
+
+
+def test_c5_two_wave_form_is_bitwise_identical_on_a_shard(c5):
+    scene, camera, tracer, depth, whole = c5
+    lib = nat.lib()
+    w, h = camera.buf_size.x, camera.buf_size.y
+    world = 64                             # 510 tiles per shard: the launch size that picks two waves
+    per = (lib.rtgs_num_tiles(w, h) + world - 1) // world
+    T = nat.tile_size()
+    outs = []
+    for flag in (nat.TRACE_SPLIT_OFF, nat.TRACE_SPLIT_ON):
+        compact = torch.zeros((per, T, T, 3), device=whole.device)
+        tracer.trace(depth, flags=flag | nat.TRACE_COMPACT, tile_first=5, tile_step=world, sample_buf=compact)
+        outs.append(compact)
+    torch.cuda.synchronize()
+    assert float(outs[0].abs().sum()) > 0 and torch.equal(outs[0], outs[1])
+    # and the shard's tiles are the whole frame's pixels
+    tiles_x = (w + T - 1) // T
+    for local in (0, per // 2, per - 2):
+        t = 5 + local * world
+        i0, j0 = (t % tiles_x) * T, (t // tiles_x) * T
+        assert torch.equal(outs[0][local, :min(T, w - i0), :min(T, h - j0)], whole[i0:i0 + T, j0:j0 + T])
+
+
+def test_c5_full_size_sanity(c5):
+    whole = c5[4]
+    assert torch.isfinite(whole).all()
+    # SH adds at most 15 * 0.05 * |Y| to a colour in [0, 1]: pixels stay in a modest range
+    assert 0.2 < float(whole.mean()) < 0.7 and float(whole.max()) <= 1.6 and float(whole.min()) >= -0.6
 
 
 # ---- edge cases and error behaviour ----
