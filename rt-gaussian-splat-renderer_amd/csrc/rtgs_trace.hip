@@ -66,6 +66,15 @@ namespace {
 #ifndef RTGS_WAVES_PER_SIMD_SH
 #define RTGS_WAVES_PER_SIMD_SH 4   // the SH variant carries 15 basis values more per lane
 #endif
+#ifndef RTGS_LDS_W
+#define RTGS_LDS_W 1      // 1: list = (t1, index|slot) registers + exponent in LDS by slot (one-wave K = 16 form)
+#endif
+#ifndef RTGS_TIER
+#define RTGS_TIER 8       // insertions touch only the first RTGS_TIER slots while slot RTGS_TIER-1 is empty in every lane (0: off)
+#endif
+#ifndef RTGS_LDS_BB
+#define RTGS_LDS_BB 0     // 1: the survivor list keeps the 16-B screen bounds in LDS; 0: indices only, bounds re-read (L1)
+#endif
 #ifndef RTGS_FAST_DIV
 #define RTGS_FAST_DIV 1   // v_rcp_f32 / v_sqrt_f32 (1 ulp) instead of IEEE division / sqrt
 #endif
@@ -84,7 +93,7 @@ struct Tune {
   static constexpr int kBlock = kWaves * kWave;             // threads per workgroup
   static constexpr int kSlabIters = (kBig ? 4 : RTGS_SLAB_ITERS) / kSplit;  // slab bounds in flight per thread
   static constexpr int kSlabStep = kSlabIters * kBlock;     // slabs scanned per barrier
-  static constexpr int kSlabCap = 2048;                      // LDS list of surviving slabs
+  static constexpr int kSlabCap = kBig ? 2048 : 768;         // LDS list of surviving slabs
   static constexpr int kSlabsPerWave = kBig ? 4 : 2;         // slabs one wave expands per batch
   static constexpr int kBatch = kSlabsPerWave * kWaves;      // slabs expanded per batch
   static constexpr int kListCap = kBatch * kSlab;            // LDS list of surviving Gaussians
@@ -409,6 +418,34 @@ __device__ __forceinline__ void list_insert_par(unsigned (&kt)[kK], unsigned (&k
   kw[0] = lt[0] ? wn : kw[0];
 }
 
+// The one-wave K = 16 form keeps only TWO register arrays per lane: the t1 bits and a payload
+// (index << 4 | slot).  The third field, the exponent delta/(4A), lives in LDS in one of the lane's
+// 16 slots; the slots of a list are a permutation of 0..15 (slot k at start), and a new entry
+// takes the slot of the entry that falls off the end, so the exponent never moves: 16 compares +
+// 64 selects instead of 16 + 96, and 32 list registers instead of 48 (96 -> 80 VGPRs).
+// kN < kK: only the first kN slots are touched -- valid while slot kN-1 is empty in every lane of
+// the wave (the caller tracks that with one ballot per insertion): lists are short for most of
+// a tile's candidates (c3: 8 hits per ray on average), and a short insertion is half the work.
+// list_insert2<kLo, kHi> updates slots kLo .. kHi-1 from the ORIGINAL values of slots kLo-1 .. kHi-1:
+// the upper range runs first (and only once the lists have grown into it), then the lower one.
+template <int kLo, int kHi, int kK>
+__device__ __forceinline__ void list_insert2(unsigned (&kt)[kK], unsigned (&kp)[kK], unsigned tn, unsigned pn) {
+  static_assert(kLo >= 0 && kLo < kHi && kHi <= kK, "range");
+  constexpr int kB = kLo > 0 ? kLo - 1 : 0;   // lowest slot compared
+  bool lt[kHi - kB];
+#pragma unroll
+  for (int k = kB; k < kHi; ++k) lt[k - kB] = tn < kt[k];
+#pragma unroll
+  for (int k = kHi - 1; k > kB; --k) {
+    kt[k] = lt[k - 1 - kB] ? kt[k - 1] : (lt[k - kB] ? tn : kt[k]);
+    kp[k] = lt[k - 1 - kB] ? kp[k - 1] : (lt[k - kB] ? pn : kp[k]);
+  }
+  if constexpr (kLo == 0) {
+    kt[0] = lt[0] ? tn : kt[0];
+    kp[0] = lt[0] ? pn : kp[0];
+  }
+}
+
 // gaussian.py:149-163, including the y_33 quirk (5 z^2 - 3 z).
 __device__ __forceinline__ void sh_basis(float x, float y, float z, float (&Y)[RTGS_SH_COEFFS]) {
   constexpr float c0 = 0.97720502380583984f, c1 = 2.1850968611841584f, c2 = 1.2615662610100802f,
@@ -458,11 +495,16 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   // the survivor list and (kSplit == 2) the list hand-over share one LDS pool: the hand-over
   // happens after the last barrier of the candidate loop
   constexpr int kMergeWords = kSplit == 2 ? kWavesPerTile * 3 * kK * kWave : 0;
-  constexpr int kListF4 = kListCap + kListCap / 4;          // float4 bounds + int indices
+  constexpr bool kLdsBb = RTGS_LDS_BB != 0;
+  constexpr int kListF4 = (kLdsBb ? kListCap : 0) + kListCap / 4;          // [float4 bounds +] int indices
   constexpr int kPoolF4 = kListF4 > kMergeWords / 4 ? kListF4 : kMergeWords / 4;
   __shared__ float4 s_pool[kPoolF4];
-  float4* const s_bb = s_pool;
-  int* const s_idx = reinterpret_cast<int*>(s_pool + kListCap);
+  [[maybe_unused]] float4* const s_bb = s_pool;
+  int* const s_idx = reinterpret_cast<int*>(s_pool + (kLdsBb ? kListCap : 0));
+  // exponents of the list entries, [slot][thread]: conflict-free whatever slots the lanes use
+  constexpr bool kLdsW = RTGS_LDS_W != 0 && kSplit == 1 && kK == RTGS_MAX_DEPTH;
+  static_assert(!kLdsW || kK == 16, "the payload keeps the slot in 4 bits");
+  __shared__ float s_w[kLdsW ? kK * kBlock : 1];
   __shared__ int s_slab[kSlabCap];
   __shared__ float s_skey[kSortMax];     // depth keys of the first kSortMax listed slabs
   __shared__ int s_wcnt[2][kWaves];
@@ -474,7 +516,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
 
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tile bounds stay in SGPRs
   const int ltile = a.tile_order ? a.tile_order[blockIdx.x] : (int)blockIdx.x;
   if ((unsigned)ltile >= gridDim.x) return;   // a malformed caller-supplied order must not write out of bounds
   const int tile = a.tile_first + ltile * a.tile_step;
@@ -513,12 +555,18 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
 
   unsigned key[kK], kidx[kK];
   constexpr unsigned kEmpty = 0x7F800000u;  // +inf
-  float wexp[kK];
+  constexpr int kWn = kLdsW ? 1 : kK;
+  float wexp[kWn];
 #pragma unroll
   for (int k = 0; k < kK; ++k) {
-    key[k] = kEmpty; wexp[k] = 0.f;
-    kidx[k] = 0u;
+    key[k] = kEmpty;
+    kidx[k] = kLdsW ? (unsigned)k : 0u;   // kLdsW: payload = index << 4 | slot
   }
+#pragma unroll
+  for (int k = 0; k < kWn; ++k) wexp[k] = 0.f;
+  [[maybe_unused]] float* const s_wl = s_w + tid;
+  constexpr int kTier = (kLdsW && RTGS_TIER > 0 && RTGS_TIER < kK) ? RTGS_TIER : kK;
+  [[maybe_unused]] bool tier_short = kTier < kK;   // wave-uniform: slot kTier-1 still empty in every lane
 
   const unsigned long long lane_lt = (1ull << lane) - 1ull;
   const int nslabs = (a.n + kSlab - 1) / kSlab;
@@ -680,7 +728,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
           const int k = b0 + q * kWaves + wave;
           const int slot = goff[q] + __popcll(gm[q] & lane_lt);
           s_idx[slot] = s_slab[k] * kSlab + lane;
-          s_bb[slot] = gb[q];
+          if constexpr (kLdsBb) s_bb[slot] = gb[q];
         }
       }
       __syncthreads();
@@ -694,7 +742,10 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
           const int slot = c + lane;
           int g = -1;
           float4 wb = make_float4(kInf, kInf, -kInf, -kInf);
-          if (slot < cnt) { g = s_idx[slot]; wb = s_bb[slot]; }
+          if (slot < cnt) {
+            g = s_idx[slot];
+            if constexpr (kLdsBb) wb = s_bb[slot]; else wb = bbox[g];
+          }
           const bool pass = wb.x <= wXhi && wb.z >= wXlo && wb.y <= wYhi && wb.w >= wYlo;
           unsigned long long m = __ballot(pass);
           [[maybe_unused]] const unsigned long long m_all = m;
@@ -788,7 +839,21 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
                 const unsigned rank = (unsigned)(turn0 + __popcll(m_all & ((1ull << b) - 1ull)));
                 entry |= rank << a.idx_bits;
               }
-              list_insert_par(key, kidx, wexp, kn, entry, wn);
+              if constexpr (kLdsW) {
+                // the new entry takes the exponent slot of the entry that falls off the end
+                const unsigned slot = (tier_short ? kidx[kTier - 1] : kidx[kK - 1]) & 15u;
+                const unsigned pn = (entry << 4) | slot;
+                if (ins) s_wl[slot * kBlock] = wn;
+                if constexpr (kTier < kK) {
+                  if (!tier_short) list_insert2<kTier, kK>(key, kidx, kn, pn);
+                }
+                list_insert2<0, kTier>(key, kidx, kn, pn);
+                if constexpr (kTier < kK) {
+                  if (tier_short) tier_short = !__any(key[kTier - 1] < kEmpty);
+                }
+              } else {
+                list_insert_par(key, kidx, wexp, kn, entry, wn);
+              }
 #endif
 #if RTGS_STAMPS
               t_ins += __builtin_amdgcn_s_memtime() - ti0;
@@ -873,31 +938,38 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   bool done = false;
 #pragma unroll
   for (int k0 = 0; k0 < kK; k0 += kGroup) {
-    if (k0 >= a.depth || done) break;
+    if (done) break;
+    // slots beyond the first `depth` only matter to lanes that dropped an exact t1 tie on the way
+    // (the reference's peel loop peels on until `depth` DISTINCT entry distances are composited)
+    if (k0 >= a.depth && !__any(nhit < a.depth && key[k0] < kEmpty)) break;
     float4 cog[kGroup];
+    [[maybe_unused]] float wl[kGroup];
 #pragma unroll
     for (int j = 0; j < kGroup; ++j) {
       const int k = k0 + j;
       const unsigned tb = key[k];
-      const unsigned gi = kSplit == 2 ? (kidx[k] & idx_mask) : kidx[k];
+      const unsigned gi = kSplit == 2 ? (kidx[k] & idx_mask) : (kLdsW ? kidx[k] >> 4 : kidx[k]);
       cog[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (tb < 0x7F800000u) cog[j] = colop[gi];
+      if (tb < kEmpty) cog[j] = colop[gi];
+      if constexpr (kLdsW) wl[j] = s_wl[(kidx[k] & 15u) * kBlock];
     }
 #pragma unroll
     for (int j = 0; j < kGroup; ++j) {
       const int k = k0 + j;
-      if (k < a.depth && !done) {
+      if (!done) {
         const unsigned tbits = key[k];
-        const unsigned gi = kSplit == 2 ? (kidx[k] & idx_mask) : kidx[k];
+        const unsigned gi = kSplit == 2 ? (kidx[k] & idx_mask) : (kLdsW ? kidx[k] >> 4 : kidx[k]);
         // an exact repeat of the previous entry distance is what the reference's strict
         // `t1 > ray.start` drops (scene.py:433 after ray_tracer.py:101)
-        const bool valid = tbits < 0x7F800000u && tbits != prev_tbits;
+        const bool valid = tbits < kEmpty && tbits != prev_tbits && nhit < a.depth;
+        // transmittance cut-off (extension, off by default): a ray below it stops compositing
+        // -- as if it had missed, ray.start = +inf -- and a wave ballot ends the loop
         const bool live = valid && !(a.t_cutoff > 0.f && T < a.t_cutoff);
         if (a.t_cutoff > 0.f && !__any(live)) { done = true; continue; }
         prev_tbits = tbits;
         float4 co = cog[j];
         if (kHasSh) {
-          if (valid) {   // (gathering for every slot, valid or not, to batch the loads: 2.24 vs 2.08 ms on c5)
+          if (live) {   // (gathering for every slot, valid or not, to batch the loads: 2.24 vs 2.08 ms on c5)
             const float* sp = sh + (size_t)gi * (RTGS_SH_COEFFS * 3);
 #pragma unroll
             for (int q = 0; q < RTGS_SH_COEFFS; ++q) {
@@ -907,8 +979,10 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
             }
           }
         }
-        const float alpha = co.w * expf(wexp[k] - 3.0f);  // == exp(-d^T S^-1 d) at the chord midpoint
-        if (valid) {
+        float wk;
+        if constexpr (kLdsW) wk = wl[j]; else wk = wexp[k];
+        const float alpha = co.w * expf(wk - 3.0f);  // == exp(-d^T S^-1 d) at the chord midpoint
+        if (live) {
           const float wa = T * alpha;
           L0 += wa * co.x; L1 += wa * co.y; L2 += wa * co.z;
           T *= 1.0f - alpha;
