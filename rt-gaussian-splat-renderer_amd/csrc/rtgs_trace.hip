@@ -61,7 +61,7 @@ namespace {
 #define RTGS_WAVES_PER_SIMD 4   // __launch_bounds__ second argument: caps VGPRs at 512/this
 #endif
 #ifndef RTGS_WAVES_PER_SIMD_MAIN
-#define RTGS_WAVES_PER_SIMD_MAIN 5   // the whole-frame instantiation (no SH, <= 4096 slabs): 96 VGPRs
+#define RTGS_WAVES_PER_SIMD_MAIN 7   // the whole-frame instantiation (no SH, <= 4096 slabs): 72 VGPRs
 #endif
 #ifndef RTGS_WAVES_PER_SIMD_SH
 #define RTGS_WAVES_PER_SIMD_SH 4   // the SH variant carries 15 basis values more per lane
@@ -72,15 +72,21 @@ namespace {
 #ifndef RTGS_TIER
 #define RTGS_TIER 8       // insertions touch only the first RTGS_TIER slots while slot RTGS_TIER-1 is empty in every lane (0: off)
 #endif
-#ifndef RTGS_LDS_BB
-#define RTGS_LDS_BB 0     // 1: the survivor list keeps the 16-B screen bounds in LDS; 0: indices only, bounds re-read (L1)
-#endif
 #ifndef RTGS_FAST_DIV
 #define RTGS_FAST_DIV 1   // v_rcp_f32 / v_sqrt_f32 (1 ulp) instead of IEEE division / sqrt
 #endif
 
 #ifndef RTGS_SLAB_ITERS
 #define RTGS_SLAB_ITERS 2
+#endif
+#ifndef RTGS_GROUP
+#define RTGS_GROUP 4
+#endif
+#ifndef RTGS_SLAB_CAP
+#define RTGS_SLAB_CAP 768
+#endif
+#ifndef RTGS_SLABS_PER_WAVE
+#define RTGS_SLABS_PER_WAVE 2
 #endif
 constexpr int kSlab = 64;                                 // Gaussians per slab = one wave
 // Batch sizes of the scan / expansion / colour-gather stages.  Measured optimum depends on the
@@ -93,11 +99,12 @@ struct Tune {
   static constexpr int kBlock = kWaves * kWave;             // threads per workgroup
   static constexpr int kSlabIters = (kBig ? 4 : RTGS_SLAB_ITERS) / kSplit;  // slab bounds in flight per thread
   static constexpr int kSlabStep = kSlabIters * kBlock;     // slabs scanned per barrier
-  static constexpr int kSlabCap = kBig ? 2048 : 768;         // LDS list of surviving slabs
-  static constexpr int kSlabsPerWave = kBig ? 4 : 2;         // slabs one wave expands per batch
-  static constexpr int kBatch = kSlabsPerWave * kWaves;      // slabs expanded per batch
-  static constexpr int kListCap = kBatch * kSlab;            // LDS list of surviving Gaussians
-  static constexpr int kGroup = kBig ? 8 : 4;                // colour/opacity gathers in flight
+  static constexpr int kSlabCap = kBig ? 2048 : RTGS_SLAB_CAP;   // LDS list of surviving slabs
+  static constexpr int kSlabsPerWave = kBig ? 4 : RTGS_SLABS_PER_WAVE;   // slabs one wave expands per batch
+  // LDS list of surviving Gaussians (indices): kWavesPerTile regions of kSlabsPerWave slabs' worth;
+  // the same in both workgroup forms, so that both see the same list order
+  static constexpr int kListCap = kSlabsPerWave * kWavesPerTile * kSlab;
+  static constexpr int kGroup = kBig ? 8 : RTGS_GROUP;       // colour/opacity gathers in flight
   static_assert(kSlabCap >= kSlabStep + 64, "slab list too small");
 };
 #ifndef RTGS_BIG_SLABS
@@ -490,25 +497,30 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   static_assert(kSplit == 1 || kSplit == 2, "one or two waves per 8x8 tile");
   using TN = Tune<kBig, kSplit>;
   constexpr int kSlabIters = TN::kSlabIters, kSlabStep = TN::kSlabStep, kSlabCap = TN::kSlabCap,
-                kSlabsPerWave = TN::kSlabsPerWave, kBatch = TN::kBatch, kListCap = TN::kListCap,
+                kSlabsPerWave = TN::kSlabsPerWave, kListCap = TN::kListCap,
                 kWaves = TN::kWaves, kBlock = TN::kBlock;
   // the survivor list and (kSplit == 2) the list hand-over share one LDS pool: the hand-over
   // happens after the last barrier of the candidate loop
   constexpr int kMergeWords = kSplit == 2 ? kWavesPerTile * 3 * kK * kWave : 0;
-  constexpr bool kLdsBb = RTGS_LDS_BB != 0;
-  constexpr int kListF4 = (kLdsBb ? kListCap : 0) + kListCap / 4;          // [float4 bounds +] int indices
+  constexpr int kListF4 = kListCap / 4;          // int indices; the 16-B bounds are re-read (L1) by the wave test
   constexpr int kPoolF4 = kListF4 > kMergeWords / 4 ? kListF4 : kMergeWords / 4;
   __shared__ float4 s_pool[kPoolF4];
-  [[maybe_unused]] float4* const s_bb = s_pool;
-  int* const s_idx = reinterpret_cast<int*>(s_pool + (kLdsBb ? kListCap : 0));
+  int* const s_idx = reinterpret_cast<int*>(s_pool);
   // exponents of the list entries, [slot][thread]: conflict-free whatever slots the lanes use
   constexpr bool kLdsW = RTGS_LDS_W != 0 && kSplit == 1 && kK == RTGS_MAX_DEPTH;
   static_assert(!kLdsW || kK == 16, "the payload keeps the slot in 4 bits");
   __shared__ float s_w[kLdsW ? kK * kBlock : 1];
   __shared__ int s_slab[kSlabCap];
-  __shared__ float s_skey[kSortMax];     // depth keys of the first kSortMax listed slabs
+  // depth keys of the first kSortMax listed slabs: only alive between the scan and the sort, when
+  // the survivor pool is idle (every batch ends with a barrier) -- they share its LDS
+  static_assert(kPoolF4 * 4 >= kSortMax, "depth keys overlay the survivor pool");
+  float* const s_skey = reinterpret_cast<float*>(s_pool);
   __shared__ int s_wcnt[2][kWaves];
-  __shared__ int s_cnt[kBatch];
+  constexpr int kRegions = kWavesPerTile;            // expander waves = regions of the survivor list
+  constexpr int kRegionCap = kListCap / kRegions;
+  constexpr int kExpand = kSlabsPerWave;             // slabs one wave has in flight
+  static_assert(kRegionCap >= kSlab, "a region must hold one whole slab");
+  __shared__ int s_rcnt[kRegions], s_rmore[kRegions];
   constexpr int kSuperStep = kSlabIters * kBlock;   // slab groups scanned per outer step
   constexpr bool kTwo = kBig || RTGS_TWO_LEVEL;   // two-level slab scan
   __shared__ int s_super[kTwo ? kSuperStep : 1];
@@ -568,7 +580,10 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   constexpr int kTier = (kLdsW && RTGS_TIER > 0 && RTGS_TIER < kK) ? RTGS_TIER : kK;
   [[maybe_unused]] bool tier_short = kTier < kK;   // wave-uniform: slot kTier-1 still empty in every lane
 
-  const unsigned long long lane_lt = (1ull << lane) - 1ull;
+  // set bits of a wave mask below this lane: v_mbcnt_lo/hi straight from the SGPR pair
+  auto below = [](unsigned long long m) -> int {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+  };
   const int nslabs = (a.n + kSlab - 1) / kSlab;
   // depth keys live behind the slab and group bounds (see slab_key_of)
   const float* const slab_key = reinterpret_cast<const float*>(slab_bbox + nslabs + (nslabs + kSuper - 1) / kSuper);
@@ -576,6 +591,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
   int c_iter = 0, c_hit = 0, c_ins = 0;
   unsigned long long t_ins = 0, t_loop0 = 0, t_front = 0;
+  const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz: calibrates the shader clock
   st[0] = __builtin_amdgcn_s_memtime();
 #endif
   int scnt = 0;  // surviving slabs listed so far: identical in every thread
@@ -612,7 +628,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
     }
 #pragma unroll
     for (int it = 0; it < kSlabIters; ++it) {
-      if ((um[it] >> lane) & 1ull) s_super[uoff + __popcll(um[it] & lane_lt)] = ub + it * kBlock + tid;
+      if ((um[it] >> lane) & 1ull) s_super[uoff + below(um[it])] = ub + it * kBlock + tid;
       uoff += __popcll(um[it]);
     }
     __syncthreads();
@@ -656,7 +672,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
 #pragma unroll
     for (int it = 0; it < kSlabIters; ++it) {
       if ((keep_m[it] >> lane) & 1ull) {
-        const int at = off + __popcll(keep_m[it] & lane_lt);
+        const int at = off + below(keep_m[it]);
         s_slab[at] = slid[it];
         if (at < kSortMax) s_skey[at] = sk[it];
       }
@@ -686,66 +702,87 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
     if (st[1] == 0) st[1] = __builtin_amdgcn_s_memtime();
 #endif
 
-#if RTGS_ABLATE == 4
-    scnt = 0;
-#endif
-    for (int b0 = 0; b0 < scnt; b0 += kBatch) {
-      // ---- expand a batch of surviving slabs: one wave per slab, one lane per Gaussian.
-      // Two passes (count, barrier, prefix, write) instead of an atomic cursor, so that the
-      // survivor list is in stream order on every run: equal t1 keys then resolve identically.
-      const int bend = min(scnt, b0 + kBatch);
-      float4 gb[kSlabsPerWave];
-      unsigned long long gm[kSlabsPerWave];
+    // ---- expand the listed slabs into the survivor list, then trace it; in ROUNDS only when the
+    // list overflows.  The kRegions expander waves each own a contiguous share of the (sorted)
+    // slab list and a region of the LDS list: no cross-wave prefix, ONE barrier between
+    // expansion and tracing, and the list order -- region by region, slab by slab, lane by lane
+    // -- is a function of the tile alone (equal t1 keys resolve identically on every run, for
+    // every sharding and in both workgroup forms).
+    const int share = (scnt + kRegions - 1) / kRegions;
+    int pos = min(scnt, wave * share);
+    const int pend = wave < kRegions ? min(scnt, (wave + 1) * share) : pos;
+    for (;;) {
+      int rcnt = 0;   // survivors this wave has listed in its region this round (wave-uniform)
+      while (pos < pend) {
+        // kExpand slabs in flight: one lane per Gaussian, 16-B bounds, coalesced
+        float4 gb[kExpand];
+        int gbase[kExpand];
 #pragma unroll
-      for (int q = 0; q < kSlabsPerWave; ++q) {
-        const int k = b0 + q * kWaves + wave;
-        gb[q] = make_float4(kInf, kInf, -kInf, -kInf);
-        if (k < bend) {
-          const int g = s_slab[k] * kSlab + lane;
-          if (g < a.n) gb[q] = bbox[g];
+        for (int q = 0; q < kExpand; ++q) {
+          gb[q] = make_float4(kInf, kInf, -kInf, -kInf);
+          gbase[q] = 0;
+          if (pos + q < pend) {
+            gbase[q] = __builtin_amdgcn_readfirstlane(s_slab[pos + q]) * kSlab;
+            if (gbase[q] + lane < a.n) gb[q] = bbox[gbase[q] + lane];
+          }
         }
-      }
+        bool full = false;
 #pragma unroll
-      for (int q = 0; q < kSlabsPerWave; ++q) {
-        const bool keep = gb[q].x <= mXhi && gb[q].z >= mXlo && gb[q].y <= mYhi && gb[q].w >= mYlo;
-        gm[q] = __ballot(keep);
-        if (lane == 0) s_cnt[q * kWaves + wave] = __popcll(gm[q]);
+        for (int q = 0; q < kExpand; ++q) {
+          if (pos < pend && !full) {
+            const bool keep = gb[q].x <= mXhi && gb[q].z >= mXlo && gb[q].y <= mYhi && gb[q].w >= mYlo;
+            const unsigned long long gm = __ballot(keep);
+            const int c = __popcll(gm);
+            if (rcnt + c > kRegionCap) {
+              full = true;   // this slab opens the next round
+            } else {
+              if (keep) s_idx[wave * kRegionCap + rcnt + below(gm)] = gbase[q] + lane;
+              rcnt += c;
+              ++pos;
+            }
+          }
+        }
+        if (full) break;
       }
+      if (lane == 0 && wave < kRegions) { s_rcnt[wave] = rcnt; s_rmore[wave] = pos < pend ? 1 : 0; }
       __syncthreads();
-      int cnt = 0;
-      int goff[kSlabsPerWave];
+      int rc[kRegions];
+      int more = 0, total = 0;
 #pragma unroll
-      for (int q = 0; q < kSlabsPerWave; ++q) {
-#pragma unroll
-        for (int w = 0; w < kWaves; ++w) {
-          if (w == wave) goff[q] = cnt;
-          cnt += s_cnt[q * kWaves + w];
-        }
+      for (int r = 0; r < kRegions; ++r) {
+        rc[r] = s_rcnt[r];
+        more |= s_rmore[r];
+        total += rc[r];
       }
-#pragma unroll
-      for (int q = 0; q < kSlabsPerWave; ++q) {
-        if ((gm[q] >> lane) & 1ull) {
-          const int k = b0 + q * kWaves + wave;
-          const int slot = goff[q] + __popcll(gm[q] & lane_lt);
-          s_idx[slot] = s_slab[k] * kSlab + lane;
-          if constexpr (kLdsBb) s_bb[slot] = gb[q];
-        }
-      }
-      __syncthreads();
-
 #if RTGS_STAMPS
       if (st[2] == 0) st[2] = __builtin_amdgcn_s_memtime();
 #endif
-      // ---- every wave: survivors vs its own 8x8 tile, then exact per-ray tests ----
-      if (wave_live) {
-        for (int c = 0; c < cnt; c += kWave) {
-          const int slot = c + lane;
-          int g = -1;
-          float4 wb = make_float4(kInf, kInf, -kInf, -kInf);
-          if (slot < cnt) {
-            g = s_idx[slot];
-            if constexpr (kLdsBb) wb = s_bb[slot]; else wb = bbox[g];
+#if RTGS_ABLATE == 4
+      total = 0;
+#endif
+      // ---- every wave: survivors vs its own 8x8 tile, then exact per-ray tests.  The regions
+      // are walked as one list; the next chunk's bounds load while this chunk's candidates run.
+      auto fetch = [&](int c, int& g, float4& wb) {
+        const int v = c + lane;
+        g = -1;
+        wb = make_float4(kInf, kInf, -kInf, -kInf);
+        if (v < total) {
+          int slot = v, base = 0;
+#pragma unroll
+          for (int r = 0; r + 1 < kRegions; ++r) {
+            base += rc[r];
+            if (v >= base) slot = v - base + (r + 1) * kRegionCap;
           }
+          g = s_idx[slot];
+          wb = bbox[g];
+        }
+      };
+      if (wave_live && total > 0) {
+        int g, gnext = -1;
+        float4 wb, wbnext = make_float4(kInf, kInf, -kInf, -kInf);
+        fetch(0, g, wb);
+        for (int c = 0; c < total; c += kWave) {
+          if (c + kWave < total) fetch(c + kWave, gnext, wbnext);
           const bool pass = wb.x <= wXhi && wb.z >= wXlo && wb.y <= wYhi && wb.w >= wYlo;
           unsigned long long m = __ballot(pass);
           [[maybe_unused]] const unsigned long long m_all = m;
@@ -860,9 +897,12 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
 #endif
             }
           }
+          g = gnext;
+          wb = wbnext;
         }
       }
-      __syncthreads();  // everyone is done with the list before the next batch refills it
+      __syncthreads();  // everyone is done with the list before the next round (or the next scan) refills it
+      if (!more) break;
     }
     scnt = 0;
   }
@@ -1007,8 +1047,9 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
 #if RTGS_STAMPS
   st[4] = __builtin_amdgcn_s_memtime();
   if (tid == 0 && a.att) {
-    unsigned long long* sp = reinterpret_cast<unsigned long long*>(a.att) + (size_t)blockIdx.x * 8;
+    unsigned long long* sp = reinterpret_cast<unsigned long long*>(a.att) + (size_t)blockIdx.x * 10;
     for (int k = 0; k < 5; ++k) sp[k] = st[k];
+    sp[8] = rt0; sp[9] = __builtin_amdgcn_s_memrealtime();
     unsigned hwid, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));

@@ -16,13 +16,18 @@ b.project()
 for world in (1, 8):
     per = (total + world - 1) // world
     compact = b.alloc(per, T, T, 3)
-    stamps = torch.zeros((per, 8), dtype=torch.int64, device="cuda")
+    stamps = torch.zeros((per, 10), dtype=torch.int64, device="cuda")
     params = nat.RtgsTraceParams(cfg.depth, 0.0, 0, world, nat.TRACE_COMPACT | (nat.TRACE_SPLIT_ON if os.environ.get('RTGS_SPLIT') == '1' else nat.TRACE_SPLIT_OFF))
     for _ in range(3):
         nat.check(nat.lib().rtgs_trace(scene.native(), camera.native(), params, nat.ptr(compact), stamps.data_ptr(),
                                        None, 1, nat.ptr(b.workspace), b.workspace.numel(), 1, nat.stream()))
     torch.cuda.synchronize()
     raw = stamps.cpu().numpy()
+    lv = raw[:, 0] > 0
+    clk = (raw[lv, 4] - raw[lv, 0]).sum() / max((raw[lv, 9] - raw[lv, 8]).sum(), 1) * 100.0
+    span_us = (raw[lv, 9].max() - raw[lv, 8].min()) / 100.0
+    print(f"   shader clock inside the kernel: {clk:.0f} MHz (s_memtime ticks per 100 MHz s_memrealtime tick, summed over workgroups); "
+          f"first start to last end {span_us:.1f} us")
     packed = raw[:, 5]
     cnts = np.stack([packed & 0xFFFF, (packed >> 16) & 0xFFFF, (packed >> 32) & 0xFFFF], axis=1).astype(np.float64)
     t_front, t_ins = raw[:, 6].astype(np.float64), raw[:, 7].astype(np.float64)
