@@ -19,7 +19,8 @@ constexpr int kWaveTile = 8;       // one wave64 owns an 8x8 pixel tile
 constexpr int kWavesX = kTile / kWaveTile;
 constexpr int kWavesPerTile = kWavesX * kWavesX;
 constexpr int kTraceBlock = kWavesPerTile * kWave;  // 256 threads for a 16x16 macro-tile
-constexpr int kRecFloats = 20;     // per-frame projected record, 80 B, 16-B aligned
+constexpr int kRecFloats = 16;     // per-frame projected record: 64 B = one cache line, one s_load_dwordx16
+constexpr int kTailFloats = 8;     // second part of the record of the (rare) general-conic / near-surface Gaussians
 constexpr float kInf = __builtin_huge_valf();
 
 // utils/quaternion.py:8-23

@@ -48,9 +48,6 @@ namespace {
 // a second slab level (1024-Gaussian groups) -12 % at 100 k Gaussians (it is what Tune<true> uses
 // above 262 k); XCD-contiguous tile chunks 0.444 (centre-heavy scene: imbalance), row-striped
 // XCD map no gain; software-pipelining insertion(k) with the test of k+1 0.329.
-#ifndef RTGS_REC_MODE
-#define RTGS_REC_MODE 1   // 1: scalar record loads where first needed; 3: whole record up front
-#endif
 #ifndef RTGS_STAMPS
 #define RTGS_STAMPS 0     // diagnostic build: per-phase s_memtime stamps of wave 0 into the buffer
 #endif                    // passed as attenuation_buf (8 x u64 per block); never quote its run time
@@ -69,6 +66,10 @@ namespace {
 #ifndef RTGS_LDS_W
 #define RTGS_LDS_W 1      // 1: list = (t1, index|slot) registers + exponent in LDS by slot (one-wave K = 16 form)
 #endif
+#ifndef RTGS_LOOKAHEAD
+#define RTGS_LOOKAHEAD 1  // big scenes: touch the next candidate's record line one iteration ahead (scalar-cache
+#endif                    // prefetch).  c5 (64 MB of records) 1.74 -> 1.58 ms; c3 (6.4 MB, L2-resident) 0.188 -> 0.192: off there
+
 #ifndef RTGS_TIER
 #define RTGS_TIER 8       // insertions touch only the first RTGS_TIER slots while slot RTGS_TIER-1 is empty in every lane (0: off)
 #endif
@@ -165,15 +166,17 @@ __global__ __launch_bounds__(256) void k_project(int32_t n, const float* __restr
                                                   float4* __restrict__ bbox,
                                                   float4* __restrict__ slab_bbox,
                                                   float* __restrict__ slab_key,
-                                                  float* __restrict__ rec) {
+                                                  float* __restrict__ rec, float* __restrict__ tail) {
   const int g0 = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = g0 < n;
   const int g = live ? g0 : n - 1;   // padding lanes recompute the last record, store nothing
   const double inf = __builtin_huge_val();
   float4 bb = make_float4(kInf, kInf, -kInf, -kInf);  // empty: culled
-  float r[kRecFloats];
+  float r[kRecFloats], tl[kTailFloats];
 #pragma unroll
   for (int k = 0; k < kRecFloats; ++k) r[k] = 0.f;
+#pragma unroll
+  for (int k = 0; k < kTailFloats; ++k) tl[k] = 0.f;
 
   const double mx = cam.o[0] - (double)pos[3 * g + 0];
   const double my = cam.o[1] - (double)pos[3 * g + 1];
@@ -308,38 +311,52 @@ __global__ __launch_bounds__(256) void k_project(int32_t n, const float* __restr
       r[0] = (float)cx;              r[1] = (float)cy;
       r[2] = (float)(cx * q0 + cy * q1 - q2);      // delta/4 at the expansion point
       // quadratic part x^T P x, P = -Q(2x2), in LDL^T form about the larger diagonal entry:
-      // d1 (x' + l y')^2 + d2 y'^2 with (x', y') = (x, y) or, flagged in r[19], (y, x).  For an
+      // d1 (x' + l y')^2 + d2 y'^2 with (x', y') = (x, y) or, flagged in the tail, (y, x).  For an
       // ellipse (P positive definite) that is a SUM OF SQUARES, so a needle a fraction of a pixel
       // wide does not lose its exponent to cancellation between p00 x^2, 2 p01 x y and p11 y^2 (a
       // 200:1 needle 0.06 px wide, 20 px from its expansion point: 2e-3 relative in delta with the
       // plain polynomial, 2e-5 this way; tools/fuzz_needles.py seed 9021).  Other conics take it
       // when the pivot dominates the off-diagonal entry (needles again); otherwise they keep the
-      // polynomial: d1 = p00, l = 0, d2 = p11 and the cross term 2 p01 in r[18].
+      // polynomial: d1 = p00, l = 0, d2 = p11 and the cross term 2 p01 in the tail.
       bool swp = false;
+      const bool ellipse = Q00 < 0.0 && det > 0.0;
+      float cross = 0.f;
       {
         const double P00 = -Q00, P01 = -Q01, P11 = -Q11;
-        const bool ellipse = Q00 < 0.0 && det > 0.0;
         swp = !ellipse && fabs(P11) > fabs(P00);   // an ellipse is a sum of squares either way
         const double piv = swp ? P11 : P00;
         if ((ellipse || fabs(piv) >= fabs(P01)) && fabs(piv) > 0.0 && fabs(piv) < inf) {
           r[5] = (float)piv;           r[6] = (float)(P01 / piv);   r[7] = (float)(det / piv);
-          r[18] = 0.f;
         } else {
           swp = false;
           r[5] = (float)P00;           r[6] = 0.f;                  r[7] = (float)P11;
-          r[18] = (float)(2.0 * P01);
+          cross = (float)(2.0 * P01);
         }
       }
       // with the flag set k_trace exchanges x and y once, so every polynomial is stored in (y, x)
-      r[19] = swp ? 1.f : 0.f;
       r[3] = (float)(2.0 * (swp ? q1 : q0));       r[4] = (float)(2.0 * (swp ? q0 : q1));   // gradient of delta/4
-      r[8] = (float)(cx * e0 + cy * e1 - e2);      // A at the expansion point
-      r[9] = (float)(2.0 * (swp ? e1 : e0));       r[10] = (float)(2.0 * (swp ? e0 : e1));
-      r[11] = (float)(swp ? Mc[1][1] : Mc[0][0]);  r[12] = (float)(2.0 * Mc[0][1]);
-      r[13] = (float)(swp ? Mc[0][0] : Mc[1][1]);
-      r[14] = (float)(v[0] * cx + v[1] * cy - v[2]);  // b = B/2 at the expansion point
-      r[15] = (float)(swp ? v[1] : v[0]);          r[16] = (float)(swp ? v[0] : v[1]);
-      r[17] = (float)C;
+      r[8] = (float)(v[0] * cx + v[1] * cy - v[2]);  // b = B/2 at the expansion point
+      r[9] = (float)(swp ? v[1] : v[0]);           r[10] = (float)(swp ? v[0] : v[1]);
+      r[11] = (float)C;
+      // A = d^T Sigma^-1 d is only needed for the exponent delta/(4A) of an inserted hit.  Since
+      // delta/4 = b^2 - A C identically, A = (b^2 - delta/4) / C: two operations on values the hit
+      // path has anyway, instead of a 6-coefficient polynomial -- and the record fits ONE 64-B
+      // cache line (one s_load_dwordx16; the scalar cache holds twice as many).  The subtraction
+      // costs 2^-22 (1 + 3/C) relative (delta/4 <= 3A on a hit), so only Gaussians with C >= 8
+      // take it; the few the camera is within ~3.3 sigma of (C < 8) and all non-elliptic conics
+      // (ellipsoids crossing the camera plane) are CLASS 1: they keep A's Taylor polynomial, the
+      // cross term and the swap flag in a 32-B tail that k_trace loads behind a scalar branch.
+      const bool compact = ellipse && C >= 8.0 && cross == 0.f && !swp;
+      r[12] = (float)(1.0 / C);
+      r[13] = compact ? 0.f : 1.f;
+      if (!compact) {
+        tl[0] = (float)(cx * e0 + cy * e1 - e2);      // A at the expansion point
+        tl[1] = (float)(2.0 * (swp ? e1 : e0));       tl[2] = (float)(2.0 * (swp ? e0 : e1));
+        tl[3] = (float)(swp ? Mc[1][1] : Mc[0][0]);   tl[4] = (float)(2.0 * Mc[0][1]);
+        tl[5] = (float)(swp ? Mc[0][0] : Mc[1][1]);
+        tl[6] = cross;
+        tl[7] = swp ? 1.f : 0.f;
+      }
     } else {
       bb = make_float4(kInf, kInf, -kInf, -kInf);
     }
@@ -350,6 +367,11 @@ __global__ __launch_bounds__(256) void k_project(int32_t n, const float* __restr
 #pragma unroll
     for (int k = 0; k < kRecFloats / 4; ++k)
       out[k] = make_float4(r[4 * k], r[4 * k + 1], r[4 * k + 2], r[4 * k + 3]);
+    if (r[13] != 0.f) {   // the tail of a compact record is never read
+      float4* to = reinterpret_cast<float4*>(tail + (size_t)g * kTailFloats);
+      to[0] = make_float4(tl[0], tl[1], tl[2], tl[3]);
+      to[1] = make_float4(tl[4], tl[5], tl[6], tl[7]);
+    }
   }
   // union bound of the slab (= this wave's 64 Gaussians); culled members are empty boxes
 #pragma unroll
@@ -492,6 +514,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
                                                           const float4* __restrict__ slab_bbox,
                                                           const float4* __restrict__ super_bbox,
                                                           const float4* __restrict__ rec,
+                                                          const float4* __restrict__ tail,
                                                           const float4* __restrict__ colop,
                                                           const float* __restrict__ sh) {
   static_assert(kSplit == 1 || kSplit == 2, "one or two waves per 8x8 tile");
@@ -577,6 +600,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
 #pragma unroll
   for (int k = 0; k < kWn; ++k) wexp[k] = 0.f;
   [[maybe_unused]] float* const s_wl = s_w + tid;
+  constexpr bool kLookahead = RTGS_LOOKAHEAD != 0 && kBig;
   constexpr int kTier = (kLdsW && RTGS_TIER > 0 && RTGS_TIER < kK) ? RTGS_TIER : kK;
   [[maybe_unused]] bool tier_short = kTier < kK;   // wave-uniform: slot kTier-1 still empty in every lane
 
@@ -801,6 +825,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
           asm volatile("" ::"s"(m));
           m = 0;
 #endif
+          [[maybe_unused]] float pf = 0.f;
           while (m) {
             const int b = __builtin_ctzll(m);
             m &= m - 1;
@@ -810,23 +835,42 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
 #endif
             // the record's address is wave-uniform: scalar loads, operands straight from SGPRs
             const int gi = __builtin_amdgcn_readlane(g, b);
-            const float4* rp = rec + (size_t)gi * (kRecFloats / 4);
-            const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3], q4 = rp[4];
-#if RTGS_REC_MODE == 3
-            // fetch the whole 80-B record before the first branch: one wait instead of three
-            asm volatile("" ::"s"(q0.x), "s"(q0.y), "s"(q0.z), "s"(q0.w), "s"(q1.x), "s"(q1.y), "s"(q1.z),
-                         "s"(q1.w), "s"(q2.x), "s"(q2.y), "s"(q2.z), "s"(q2.w), "s"(q3.x), "s"(q3.y),
-                         "s"(q3.z), "s"(q3.w), "s"(q4.x), "s"(q4.y));
-#endif
-            // delta/4 = e_c + g.(x',y') - d1 (x' + l y')^2 - d2 y'^2 - cr x y about the record's
-            // expansion point, (x', y') = (x, y) or (y, x) (k_project: LDL^T about the larger pivot)
+            // one 64-B line, ONE s_load_dwordx16 (loaded as a single vector so that the compiler
+            // cannot sink part of it behind the first branch and wait twice)
+            typedef float Rec16 __attribute__((ext_vector_type(16)));
+            const Rec16 rq = *reinterpret_cast<const Rec16*>(rec + (size_t)gi * (kRecFloats / 4));
+            const float4 q0 = make_float4(rq[0], rq[1], rq[2], rq[3]), q1 = make_float4(rq[4], rq[5], rq[6], rq[7]),
+                         q2 = make_float4(rq[8], rq[9], rq[10], rq[11]), q3 = make_float4(rq[12], rq[13], rq[14], rq[15]);
+            // delta/4 = e_c + g.(x',y') - d1 (x' + l y')^2 - d2 y'^2 [- cr x y] about the record's
+            // expansion point (k_project: LDL^T about the larger pivot)
             float x = X - q0.x;
             float y = Y - q0.y;
-            // records of non-elliptic conics pivoted on p11 are stored in (y, x): a real (scalar)
-            // branch around one v_swap_b32, not two selects on every candidate (0.283 vs 0.274 ms)
-            if (__builtin_expect(q4.w != 0.f, 0)) asm volatile("v_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+            float gx = q0.w;
+            if constexpr (kLookahead) {
+              // Look-ahead: one dword of the NEXT candidate's record, issued once this record has
+              // arrived (the asm ties the address to its first use), so that the line is in the
+              // scalar cache -- 55 % hit rate without -- when the next iteration asks for it.  The
+              // value itself is only kept alive until then.
+              asm volatile("" ::"s"(pf));
+              if (m) {
+                int gn = __builtin_amdgcn_readlane(g, __builtin_ctzll(m));
+                asm volatile("" : "+s"(gn) : "v"(x));
+                pf = *reinterpret_cast<const float*>(rec + (size_t)gn * (kRecFloats / 4));
+              }
+            }
+            // class 1 (general conic, or the camera within ~3.3 sigma): cross term, (y, x) storage
+            // and A's own polynomial come from the tail, behind a scalar branch
+            const bool gen = q3.y != 0.f;
+            float A_gen = 0.f;
+            if (__builtin_expect(gen, 0)) {
+              const float4* tp = tail + (size_t)gi * (kTailFloats / 4);
+              const float4 t0 = tp[0], t1v = tp[1];
+              if (t1v.w != 0.f) asm volatile("v_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+              gx = fmaf(-t1v.z, y, q0.w);
+              A_gen = fmaf(y, fmaf(t1v.y, y, t0.z), fmaf(x, fmaf(t1v.x, y, fmaf(t0.w, x, t0.y)), t0.x));
+            }
             const float u = fmaf(q1.z, y, x);
-            float e = fmaf(x, fmaf(-q4.z, y, q0.w), q0.z);
+            float e = fmaf(x, gx, q0.z);
             e = fmaf(y, fmaf(-q1.w, y, q1.x), e);
             e = fmaf(-(q1.y * u), u, e);
             bool hit = e > 0.f && in_img;
@@ -841,16 +885,15 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
             // explicit fma chains: every instantiation (K = 1 / 16, one or two waves, SH or not)
             // must round t1 and the exponent identically, or two hits one ulp apart in t1 could
             // composite in a different order in a progressive sample() than in a one-pass trace
-            const float A = fmaf(y, fmaf(q3.y, y, q2.z), fmaf(x, fmaf(q3.x, y, fmaf(q2.w, x, q2.y)), q2.x));
-            const float bq = fmaf(q4.x, y, fmaf(q3.w, x, q3.z));
+            const float bq = fmaf(q2.z, y, fmaf(q2.y, x, q2.x));
             hit = hit && bq < 0.f;   // the cone half in front of the camera
             // smaller root of A t^2 + 2 b t + C (gaussian.py:224) in its cancellation-free form
             // t1 = C / (sqrt(delta/4) - b): C > 0 and b < 0, so nothing is subtracted.
             // v_sqrt_f32 / v_rcp_f32 are 1 ulp: far inside the 1e-4 pixel tolerance.
 #if RTGS_FAST_DIV
-            const float t1 = q4.y * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(e) - bq) * dlen;
+            const float t1 = q2.w * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(e) - bq) * dlen;
 #else
-            const float t1 = (q4.y / (sqrtf(e) - bq)) * dlen;
+            const float t1 = (q2.w / (sqrtf(e) - bq)) * dlen;
 #endif
             const bool cand = hit && t1 > start && t1 < kInf;  // scene.py:433
             const unsigned kn = cand ? __float_as_uint(t1) : ~0u;
@@ -861,6 +904,8 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
               const unsigned long long ti0 = __builtin_amdgcn_s_memtime();
               t_front += ti0 - t_loop0;
 #endif
+              // A = d^T Sigma^-1 d from delta/4 = b^2 - A C (compact records), or its own polynomial
+              const float A = gen ? A_gen : fmaf(bq, bq, -e) * q3.x;
 #if RTGS_FAST_DIV
               const float wn = e * __builtin_amdgcn_rcpf(A);
 #else
@@ -1093,7 +1138,7 @@ size_t rtgs_workspace_bytes(int32_t n) {
   if (n <= 0) return 0;
   const size_t nn = ((size_t)n + 63) & ~(size_t)63;
   const size_t nslabs = nn / kSlab, nsuper = (nslabs + kSuper - 1) / kSuper;
-  return nn * sizeof(float4) + nn * kRecFloats * sizeof(float) + (nslabs + nsuper) * sizeof(float4) +
+  return nn * sizeof(float4) + nn * (kRecFloats + kTailFloats) * sizeof(float) + (nslabs + nsuper) * sizeof(float4) +
          ((nslabs + 3) & ~(size_t)3) * sizeof(float);
 }
 
@@ -1110,7 +1155,7 @@ int32_t rtgs_num_local_tiles(int32_t width, int32_t height, int32_t tile_first, 
   return (total - tile_first + tile_step - 1) / tile_step;
 }
 
-// workspace: [bbox nn x float4][records nn x 20 float][slab bounds][group bounds][slab depth keys]
+// workspace: [bbox nn x float4][records nn x 16 float][tails nn x 8 float][slab bounds][group bounds][slab depth keys]
 static float* slab_key_of(float4* slab_bbox, size_t nn) {
   const size_t nslabs = nn / kSlab, nsuper = (nslabs + kSuper - 1) / kSuper;
   return reinterpret_cast<float*>(slab_bbox + nslabs + nsuper);
@@ -1132,12 +1177,13 @@ int rtgs_project(const RtgsScene* scene, const RtgsCamera* cam, void* workspace,
   const size_t nn = ((size_t)scene->n + 63) & ~(size_t)63;
   float4* bbox = static_cast<float4*>(workspace);
   float* rec = reinterpret_cast<float*>(bbox + nn);
-  float4* slab_bbox = reinterpret_cast<float4*>(rec + nn * kRecFloats);
+  float* tail = rec + nn * kRecFloats;
+  float4* slab_bbox = reinterpret_cast<float4*>(tail + nn * kTailFloats);
   const FrameCam fc = make_frame_cam(*cam);
   const int block = 256;
   hipLaunchKernelGGL(k_project, dim3((scene->n + block - 1) / block), dim3(block), 0,
                      static_cast<hipStream_t>(stream), scene->n, scene->position, scene->rotation,
-                     scene->scale, fc, bbox, slab_bbox, slab_key_of(slab_bbox, nn), rec);
+                     scene->scale, fc, bbox, slab_bbox, slab_key_of(slab_bbox, nn), rec, tail);
   const int nslabs = (int)(nn / kSlab);
   if (nslabs > kBigSceneSlabs || RTGS_TWO_LEVEL) {
     const int nsuper = (nslabs + kSuper - 1) / kSuper;
@@ -1184,7 +1230,8 @@ static int trace_impl(const RtgsScene* scene, const RtgsCamera* cam, const RtgsT
   for (int k = 0; k < 9; ++k) a.rc[k] = (float)fc.rc[k];
   const float4* bbox = static_cast<const float4*>(workspace);
   const float4* rec = bbox + nn;
-  const float4* slab_bbox = rec + nn * (kRecFloats / 4);
+  const float4* tail = rec + nn * (kRecFloats / 4);
+  const float4* slab_bbox = tail + nn * (kTailFloats / 4);
   const float4* super_bbox = slab_bbox + nn / kSlab;
   const float4* colop = reinterpret_cast<const float4*>(scene->color_opacity);
   a.sample = sample_buf;
@@ -1206,7 +1253,7 @@ static int trace_impl(const RtgsScene* scene, const RtgsCamera* cam, const RtgsT
   if (params->depth == 1) split = false;
 #define RTGS_LAUNCH(HAS_SH, BIG, K, SPLIT)                                                         \
   hipLaunchKernelGGL((k_trace<HAS_SH, BIG, K, SPLIT>), dim3(local), dim3(kTraceBlock * SPLIT), 0, s, a, \
-                     bbox, slab_bbox, super_bbox, rec, colop, sh)
+                     bbox, slab_bbox, super_bbox, rec, tail, colop, sh)
 #define RTGS_LAUNCH_K(HAS_SH, BIG)                                                  \
   do {                                                                              \
     if (params->depth == 1) RTGS_LAUNCH(HAS_SH, BIG, 1, 1);                         \
