@@ -28,6 +28,14 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+# VALU issue peak: 256 CUs x 4 SIMDs, one wave64 VALU instruction per SIMD every 2 cycles
+# (SIMD-32: MI355X_MICROARCH.md "v_fma_f32 (wave64) 2 cyc"), at the 2.4 GHz peak engine clock.
+# (Inside k_trace the clock measures 2.14 GHz -- s_memtime against the 100 MHz s_memrealtime,
+# tools/stamps.py, profiles/r02_c3_phase_stamps.txt; the fraction below is against the 2.4 GHz peak.)
+N_SIMD = 1024
+ENGINE_CLOCK_HZ = 2.4e9
+VALU_PEAK_GINST = N_SIMD * ENGINE_CLOCK_HZ / 2 / 1e9   # G wave-instructions / s
+PROFILE_ROUND = "r02"
 
 
 def parse():
@@ -77,17 +85,20 @@ def cpu_baseline(cfg, arrays, cam, n_rays):
     return out
 
 
-def profiled_traffic(cfg_name, world):
-    """HBM bytes per k_trace launch from the committed rocprofv3 PMC summary of the same
-    command (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE; separate --pmc passes).
-    Counters cannot be read from inside the bench, so this is the profiled value, or None."""
-    path = os.path.join(ROOT, "profiles", f"r01_{cfg_name}_summary.json")
+def profiled_counters(cfg_name, world):
+    """Per-launch k_trace counters from the committed rocprofv3 PMC summary of the same command
+    and build (tools/prof.sh + tools/summarize_prof.py; separate --pmc passes): SQ_INSTS_VALU, and
+    the HBM bytes (FETCH_SIZE x2 per the guide's gfx950 correction + WRITE_SIZE).  Counters cannot
+    be read from inside the bench, so these are the profiled values, or None when the profile of
+    this config is not committed."""
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{cfg_name}_summary.json")
     if world != 1 or not os.path.exists(path):
-        return None, None
+        return None, None, None
     with open(path) as f:
         summary = json.load(f)
     t = summary.get("k_trace_hbm_bytes_per_launch")
-    return (t["traffic_upper"], os.path.relpath(path, ROOT)) if t else (None, None)
+    pmc = summary.get("kernels", {}).get("k_trace", {}).get("pmc_mean_per_launch", {})
+    return pmc.get("SQ_INSTS_VALU"), (t["traffic_upper"] if t else None), os.path.relpath(path, ROOT)
 
 
 def main():
@@ -115,6 +126,7 @@ def main():
     from rtgs import _native as nat
     from rtgs import synthetic
     from rtgs.parallel import TileParallelRenderer
+    from rtgs.utils.types import vec3
 
     cfg = synthetic.CONFIGS[args.config]
     arrays = synthetic.make_config_scene(cfg)
@@ -175,24 +187,47 @@ def main():
         torch.cuda.synchronize()
         frame_ms_median = sorted(a_.elapsed_time(b_) for a_, b_ in evs)[len(evs) // 2]
 
+    # N > 1: two consecutive frames with DIFFERENT camera poses go through the double-buffered
+    # pipeline and must equal single-rank renders of the same poses bit for bit (a stale or
+    # swapped half of the double buffer would show here)
     verified = None
-    if world > 1 and rank == 0:
-        # the gathered, de-interleaved frame must equal a single-rank render of the same frame
-        single = TileParallelRenderer(scene, camera, depth=cfg.depth, rank=0, world=1)
-        single.render_frame()
-        single.finish()
+    if world > 1:
+        poses = [(0.15, -0.1, 3.0), tuple(cam["position"])]
+        frames = []
+        for k, p in enumerate(poses):
+            camera.position = vec3(p)
+            renderer.render_frame()
+            if k > 0 and rank == 0:
+                torch.cuda.synchronize()
+                frames.append(renderer.framebuffer.clone())       # frame k-1 has just been completed
+        renderer.finish()
         torch.cuda.synchronize()
-        verified = bool(torch.equal(single.framebuffer, renderer.framebuffer))
+        if rank == 0:
+            frames.append(renderer.framebuffer.clone())
+            single = TileParallelRenderer(scene, camera, depth=cfg.depth, rank=0, world=1)
+            verified = True
+            for p, got in zip(poses, frames):
+                camera.position = vec3(p)
+                single.render_frame()
+                single.finish()
+                torch.cuda.synchronize()
+                verified = verified and bool(torch.equal(single.framebuffer, got))
+        camera.position = vec3(cam["position"])
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         mrays = cfg.rays / (elapsed / args.steps) / 1e6
         bpr = synthetic.bytes_per_ray(cfg.n, cfg.sh, cfg.depth)
         local_rays = renderer.local_tiles * nat.tile_size() ** 2
-        achieved = bpr * min(local_rays, cfg.rays) / (trace_ms * 1e-3) / 1e9  # GB/s, this rank's launch
-        traffic, traffic_src = profiled_traffic(cfg.name, world)
+        streamed = bpr * min(local_rays, cfg.rays) / (trace_ms * 1e-3) / 1e9  # GB/s of the SURVEY 8(d) model
+        valu, traffic, src = profiled_counters(cfg.name, world)
+        achieved = valu / (trace_ms * 1e-3) / 1e9 if valu else None
+        hbm_gbs = traffic / (trace_ms * 1e-3) / 1e9 if traffic else None
+        base_metric = "Mrays/s at 1920x1080, 100k Gaussians; achieved HBM GB/s vs peak"
+        metric = base_metric if (cfg.width, cfg.height, cfg.n) == (1920, 1080, 100_000) else \
+            f"Mrays/s at {cfg.width}x{cfg.height}, {cfg.n} Gaussians; achieved HBM GB/s vs peak"
         line = {
-            "metric": "Mrays/s at 1920x1080, 100k Gaussians; achieved HBM GB/s vs peak",
+            "metric": metric,
             "value": mrays, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -201,15 +236,24 @@ def main():
                                    f"{'SH deg 3' if cfg.sh else 'no SH'}, camera (0,0,3) f=H",
                        "rays_per_frame": cfg.rays, "gaussians": cfg.n,
                        "parallelism": f"tile-parallel x{world}" + (" + RCCL gather" if world > 1 else "")},
-            "roofline": {"bound": "hbm", "kernel": "k_trace", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_unit": "bytes per k_trace launch",
-                         "traffic_source": traffic_src, "kernel_ms": trace_ms,
-                         "project_ms": project_ms,
+            # k_trace is a VALU-issue kernel (screen-space culling leaves ~0.03 % of the ray x
+            # Gaussian pairs; HBM carries < 10 % of its peak): the bound it can fail is the VALU
+            # issue rate.  achieved = SQ_INSTS_VALU per launch (committed profile of this build and
+            # config) / the kernel time measured live here with HIP events on the launch stream.
+            "roofline": {"bound": "valu", "kernel": "k_trace", "achieved": achieved,
+                         "peak": VALU_PEAK_GINST, "unit": "G wave64-instr/s",
+                         "frac": (achieved / VALU_PEAK_GINST) if achieved else None,
+                         "traffic": traffic, "traffic_unit": "HBM bytes per k_trace launch (PMC)",
+                         "hbm_achieved_gbs": hbm_gbs, "hbm_peak_gbs": HBM_PEAK_GBS,
+                         "hbm_frac": (hbm_gbs / HBM_PEAK_GBS) if hbm_gbs else None,
+                         "valu_insts_per_launch": valu, "counters_source": src,
+                         "kernel_ms": trace_ms, "project_ms": project_ms,
                          "algorithmic_bytes_per_ray": bpr,
-                         "note": "achieved = SURVEY 8(d) streamed bytes/ray x rays per launch / "
-                                 "k_trace time; screen-space culling skips most of that stream, "
-                                 "so frac > 1 is possible; physical HBM bytes: profiles/"},
+                         "speedup_vs_streamed_model": streamed / HBM_PEAK_GBS,
+                         "note": "frac = VALU wave-instructions issued / (1024 SIMDs x 2.4 GHz / 2). "
+                                 "speedup_vs_streamed_model = SURVEY 8(d)'s every-tile-streams-every-"
+                                 "Gaussian byte count / kernel time / 8 TB/s: not a roofline fraction, "
+                                 "the kernel culls that stream instead of performing it."},
         }
         line["secondary"] = {"closest_hit_queries_per_s": mrays * 1e6 * cfg.depth,
                              "frame_ms_median_hip_events": frame_ms_median}

@@ -31,7 +31,8 @@ def _f32(a):
     return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
 
 
-def render(arrays: dict, cam: dict, depth: int, pixels=None, eps_q=1e-5, eps_t=1e-6) -> dict:
+def render(arrays: dict, cam: dict, depth: int, pixels=None, eps_q=1e-5, eps_t=1e-6, t_cutoff=0.0,
+           eps_c=1e-6) -> dict:
     """fp64 one-pass render of `pixels` ((n,2) int (i,j); default: the whole (W,H) frame, i major).
     Same return keys as rtgs_ref.render_topk (sample, attenuation, start, hits, margins, fragile)."""
     lib = _load()
@@ -46,13 +47,13 @@ def render(arrays: dict, cam: dict, depth: int, pixels=None, eps_q=1e-5, eps_t=1
     n = pos.shape[0]
     cp, cr = _f32(cam["position"]), _f32(cam["rotation"])
     sample = np.zeros((n_pix, 3)); att = np.zeros(n_pix); start = np.zeros(n_pix)
-    hits = np.zeros(n_pix, dtype=np.int32); mq = np.zeros(n_pix); mt = np.zeros(n_pix)
+    hits = np.zeros(n_pix, dtype=np.int32); mq = np.zeros(n_pix); mt = np.zeros(n_pix); mc = np.zeros(n_pix)
     P = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
     rc = lib.rtgs_oracle_render(ctypes.c_int(n), P(pos), P(rot), P(sc), P(col), P(opa), P(sh), P(cp), P(cr),
                                 ctypes.c_int(W), ctypes.c_int(H), ctypes.c_float(cam["fx"]),
                                 ctypes.c_float(cam["fy"]), ctypes.c_int(depth), ctypes.c_int(n_pix), P(pix),
-                                P(sample), P(att), P(start), P(hits), P(mq), P(mt))
+                                P(sample), P(att), P(start), P(hits), P(mq), P(mt), ctypes.c_double(t_cutoff), P(mc))
     if rc != 0:
         raise RuntimeError(f"rtgs_oracle_render failed: {rc}")
     return dict(sample=sample, attenuation=att, start=start, hits=hits.astype(np.int64), margin_q=mq,
-                margin_t=mt, fragile=(mq < eps_q) | (mt < eps_t))
+                margin_t=mt, margin_c=mc, fragile=(mq < eps_q) | (mt < eps_t) | (mc < eps_c))

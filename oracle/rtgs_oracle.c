@@ -90,12 +90,15 @@ static void sh_basis(const double* d, double* Y) { /* gaussian.py:17-23, 149-163
 /* Returns 0 on success.  All array arguments are host pointers.
  * sample[n_pix][3], attenuation[n_pix], start[n_pix] (t1 of the last peel or +inf), hits[n_pix],
  * margin_q / margin_t [n_pix]: distance of the pixel from a discontinuity of the image function
- * (see rtgs_ref.render_topk). */
+ * (see rtgs_ref.render_topk).
+ * t_cutoff > 0 (an extension of the build; the reference has no early-out, ray_tracer.py:79-104):
+ * a ray whose attenuation is below t_cutoff composites nothing more; margin_c [n_pix] (may be
+ * NULL) = the closest an attenuation on the way came to t_cutoff, relative. */
 int rtgs_oracle_render(int n, const float* pos, const float* rot, const float* scale, const float* color,
                        const float* opacity, const float* sh /* [n][15][3] or NULL */, const float* cam_pos,
                        const float* cam_rot, int W, int H, float fx, float fy, int depth, int n_pix,
                        const int* pixels, double* sample, double* attenuation, double* start, int* hits,
-                       double* margin_q, double* margin_t) {
+                       double* margin_q, double* margin_t, double t_cutoff, double* margin_c) {
   if (n <= 0 || depth < 1 || depth > 64 || n_pix < 0) return -1;
   double* M = (double*)malloc(sizeof(double) * 9 * (size_t)n);
   if (!M) return -2;
@@ -107,7 +110,9 @@ int rtgs_oracle_render(int n, const float* pos, const float* rot, const float* s
   }
   const double o[3] = {cam_pos[0], cam_pos[1], cam_pos[2]};
   const double cq[4] = {cam_rot[0], cam_rot[1], cam_rot[2], cam_rot[3]};
-  const int K = depth + 1;
+  /* depth + 1 entries decide the image and its margins; up to 8 more let the walk below pass
+   * exact t1 ties, as the reference's peel loop does (it peels on until `depth` distinct hits) */
+  const int K = depth + 9 > 65 ? 65 : depth + 9;
 #pragma omp parallel for schedule(dynamic, 16)
   for (int p = 0; p < n_pix; ++p) {
     /* camera.py:57-71 */
@@ -137,7 +142,7 @@ int rtgs_oracle_render(int n, const float* pos, const float* rot, const float* s
       while (k > 0 && kt[k - 1] > t1) { kt[k] = kt[k - 1]; kt2[k] = kt2[k - 1]; ki[k] = ki[k - 1]; --k; }
       kt[k] = t1; kt2[k] = t2; ki[k] = g;
     }
-    double L[3] = {0, 0, 0}, T = 1.0, last = 0.0, prev = -1.0, mt = INFINITY;
+    double L[3] = {0, 0, 0}, T = 1.0, last = 0.0, prev = -1.0, mt = INFINITY, mc = INFINITY;
     int nh = 0;
     double Y[SH_COEFFS];
     if (sh) {
@@ -145,14 +150,19 @@ int rtgs_oracle_render(int n, const float* pos, const float* rot, const float* s
       const double dn[3] = {d[0] / l2, d[1] / l2, d[2] / l2}; /* gaussian.py:200 */
       sh_basis(dn, Y);
     }
-    for (int k = 0; k + 1 < K; ++k) { /* gap relative to max(1, t1): fp32 error of t1 grows with t1 */
+    for (int k = 0; k < depth; ++k) { /* gap relative to max(1, t1): fp32 error of t1 grows with t1 */
       const double gap = (kt[k + 1] - kt[k]) / fmax(1.0, kt[k + 1]);
       if (isfinite(kt[k + 1]) && gap < mt) mt = gap;
     }
-    for (int k = 0; k < K - 1 && nh < depth; ++k) {
+    for (int k = 0; k < K && nh < depth; ++k) {
       if (!isfinite(kt[k])) break;
       if (kt[k] == prev) continue;
       prev = kt[k];
+      if (t_cutoff > 0.0) {
+        const double c = fabs(T - t_cutoff) / t_cutoff;
+        if (c < mc) mc = c;
+        if (T < t_cutoff) break; /* terminated: as after a miss */
+      }
       const int g = ki[k];
       const double tm = 0.5 * (kt[k] + kt2[k]); /* ray_tracer.py:89 */
       const double x[3] = {o[0] + tm * d[0] - pos[3 * g], o[1] + tm * d[1] - pos[3 * g + 1],
@@ -173,6 +183,7 @@ int rtgs_oracle_render(int n, const float* pos, const float* rot, const float* s
     hits[p] = nh;
     margin_q[p] = mq;
     margin_t[p] = mt;
+    if (margin_c) margin_c[p] = mc;
   }
   free(M);
   return 0;

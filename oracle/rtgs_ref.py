@@ -392,7 +392,7 @@ def _shade(scene, origin, dirs, idx, t1, t2):
 
 
 def render_peel(scene, cam_position, cam_rotation, width, height, fx, fy, depth=16,
-                pixels=None, state=None, steps=None, absorb_eps=None):
+                pixels=None, state=None, steps=None, absorb_eps=None, t_cutoff=0.0):
     """The reference's literal loop (ray_tracer.py:39-54, 79-104): `depth` closest-hit peels,
     each evaluating the hit Gaussian at its chord midpoint and advancing ray.start.
 
@@ -404,6 +404,10 @@ def render_peel(scene, cam_position, cam_rotation, width, height, fx, fy, depth=
     for t1 >~ 0.17, so the next peel's strict `t1 > start` (scene.py:433) is what excludes the
     same Gaussian.  The fp64 golden keeps that *observable* behaviour by advancing start to
     t1 exactly (absorb_eps=True, default for float64); float32 applies the literal addition.
+
+    t_cutoff > 0 (an EXTENSION of the build, the reference has none: ray_tracer.py:79-104): a ray
+    whose attenuation has fallen below t_cutoff is terminated -- it composites nothing more and
+    its start becomes +inf, exactly as after a miss.
     """
     dt = scene.dtype
     if absorb_eps is None:
@@ -421,6 +425,8 @@ def render_peel(scene, cam_position, cam_rotation, width, height, fx, fy, depth=
     for _ in range(depth if steps is None else steps):
         idx, t1, t2 = closest_hit(scene, origin, dirs, start, inf)
         hit = idx >= 0
+        if t_cutoff > 0:
+            hit &= ~(att < dt(t_cutoff))
         if hit.any():
             h = np.nonzero(hit)[0]
             rgb, alpha = _shade(scene, origin, dirs[h], idx[h], t1[h], t2[h])
@@ -455,7 +461,7 @@ def sample_step_rays(scene, rays, sample, attenuation, absorb_eps=None):
 
 
 def render_topk(scene, cam_position, cam_rotation, width, height, fx, fy, depth=16,
-                pixels=None, chunk=None, eps_q=1e-5, eps_t=1e-6):
+                pixels=None, chunk=None, eps_q=1e-5, eps_t=1e-6, t_cutoff=0.0, eps_c=1e-6):
     """SURVEY.md Appendix A.9 -- the one-pass form of the same image: the <= depth Gaussians
     with the smallest entry distance t1 > 0, sorted ascending, composited front to back, with
     alpha = opacity * exp(delta/(4A) - 3) (== the chord-midpoint evaluation of gaussian.py:197).
@@ -467,6 +473,10 @@ def render_topk(scene, cam_position, cam_rotation, width, height, fx, fy, depth=
                  to max(1, t1) (an fp32 t1 carries a few ulp of error, which grows with t1).
     `fragile` = margin_q < eps_q or margin_t < eps_t: an fp32 renderer may legitimately take
     the other branch there.
+
+    t_cutoff > 0 (extension, see render_peel): a ray stops compositing once its attenuation is
+    below t_cutoff.  margin_c = the closest any attenuation on the way came to t_cutoff, relative;
+    below eps_c the pixel is fragile too (an fp32 attenuation may fall on the other side).
     """
     dt = scene.dtype
     origin, dirs = generate_rays(cam_position, cam_rotation, width, height, fx, fy, pixels, dt)
@@ -501,10 +511,16 @@ def render_topk(scene, cam_position, cam_rotation, width, height, fx, fy, depth=
     if scene.sh is not None:
         ray_sh = sh_basis(dirs / np.sqrt(np.sum(dirs * dirs, axis=-1, keepdims=True)), dt)
     prev_t = np.full(n, -1.0, dtype=dt)
+    margin_c = np.full(n, np.inf, dtype=dt)
+    dead = np.zeros(n, dtype=bool)
     for k in range(K):
         # an exact repeat of the previous entry distance is dropped: the reference's strict
         # `t1 > ray.start` (scene.py:433) cannot see it after ray_tracer.py:101
         valid = np.isfinite(keep_t[:, k]) & (keep_t[:, k] != prev_t) & (hits < depth)
+        if t_cutoff > 0:
+            margin_c = np.where(valid & ~dead, np.minimum(margin_c, np.abs(att - t_cutoff) / t_cutoff), margin_c)
+            dead |= valid & (att < dt(t_cutoff))
+            valid &= ~dead
         prev_t = np.where(np.isfinite(keep_t[:, k]), keep_t[:, k], prev_t)
         h = np.nonzero(valid)[0]
         if h.size == 0:
@@ -524,8 +540,8 @@ def render_topk(scene, cam_position, cam_rotation, width, height, fx, fy, depth=
     margin_t = np.min(gaps, axis=1) if K > 1 else np.full(n, np.inf)
     start = np.where(hits == depth, last_t, np.inf).astype(dt)
     return dict(sample=sample, attenuation=att, start=start, hits=hits, idx=keep_i[:, :depth],
-                t1=keep_t[:, :depth], margin_q=margin_q, margin_t=margin_t,
-                fragile=(margin_q < eps_q) | (margin_t < eps_t))
+                t1=keep_t[:, :depth], margin_q=margin_q, margin_t=margin_t, margin_c=margin_c,
+                fragile=(margin_q < eps_q) | (margin_t < eps_t) | (margin_c < eps_c))
 
 
 def disp_buffer(sample, num_samples, num_steps, num_depth, dtype=np.float64):

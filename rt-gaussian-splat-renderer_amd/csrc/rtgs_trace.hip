@@ -600,7 +600,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
 #pragma unroll
   for (int k = 0; k < kWn; ++k) wexp[k] = 0.f;
   [[maybe_unused]] float* const s_wl = s_w + tid;
-  constexpr bool kLookahead = RTGS_LOOKAHEAD != 0 && kBig;
+  constexpr bool kLookahead = RTGS_LOOKAHEAD == 2 || (RTGS_LOOKAHEAD == 1 && kBig);
   constexpr int kTier = (kLdsW && RTGS_TIER > 0 && RTGS_TIER < kK) ? RTGS_TIER : kK;
   [[maybe_unused]] bool tier_short = kTier < kK;   // wave-uniform: slot kTier-1 still empty in every lane
 

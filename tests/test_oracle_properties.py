@@ -105,6 +105,55 @@ def test_c_oracle_matches_numpy_oracle():
         assert (a["hits"] == c["hits"]).all() and (a["fragile"] == c["fragile"]).all(), name
 
 
+def test_transmittance_cutoff_is_the_same_in_all_three_forms():
+    # the cut-off is the build's extension (the reference has none, ray_tracer.py:79-104): a ray
+    # below it stops as after a miss.  Literal peel loop == one-pass NumPy == C, and it does cut.
+    arrays, cam, depth = scenes.CASES["shallow"]()
+    pix = scenes.crop_pixels(cam["width"], cam["height"], 20, 20, extra=100)
+    osc = ref.OracleScene(**arrays)
+    args = (osc, cam["position"], cam["rotation"], cam["width"], cam["height"], cam["fx"], cam["fy"])
+    for cut in (0.4, 0.7):
+        a = ref.render_peel(*args, depth=depth, pixels=pix, t_cutoff=cut)
+        b = ref.render_topk(*args, depth=depth, pixels=pix, t_cutoff=cut)
+        c = c_oracle.render(arrays, cam, depth, pix, t_cutoff=cut)
+        for other in (b, c):
+            assert np.abs(a["sample"] - other["sample"]).max() < 1e-9
+            assert np.abs(a["attenuation"] - other["attenuation"]).max() < 1e-9
+            assert (a["hits"] == other["hits"]).all()
+            assert (np.isfinite(a["start"]) == np.isfinite(other["start"])).all()
+        assert np.allclose(b["margin_c"], c["margin_c"], rtol=1e-9, atol=1e-10) and (b["fragile"] == c["fragile"]).all()
+        # every terminated ray ends below the cut-off after one more contribution at most
+        full = ref.render_topk(*args, depth=depth, pixels=pix)
+        cut_rays = b["hits"] < full["hits"]
+        assert cut_rays.any() and (b["attenuation"][cut_rays] < cut).all()
+        assert (b["attenuation"][~cut_rays] == full["attenuation"][~cut_rays]).all()
+    zero = ref.render_topk(*args, depth=depth, pixels=pix, t_cutoff=0.0)
+    assert np.array_equal(zero["sample"], ref.render_topk(*args, depth=depth, pixels=pix)["sample"])
+
+
+def test_exact_ties_do_not_use_up_peels():
+    # duplicated Gaussians give exactly equal t1: the reference's strict `t1 > ray.start`
+    # (scene.py:433 after ray_tracer.py:101) drops the twin and the loop peels on until `depth`
+    # DISTINCT entry distances are composited; the one-pass forms must walk past the twins too
+    base = synthetic.make_scene(40, 1.0, 5)
+    base["scale"] = (base["scale"] * np.float32(2.0)).astype(np.float32)
+    arrays = {k: (None if v is None else np.concatenate([v, v[:25]])) for k, v in base.items()}
+    cam = synthetic.bench_camera(24, 24)
+    for depth in (3, 6):
+        a = peel(arrays, cam, depth)
+        b = topk(arrays, cam, depth)
+        c = c_oracle.render(arrays, cam, depth)
+        d = peel(base, cam, depth)
+        assert (a["hits"] == d["hits"]).all() and (c["hits"] == a["hits"]).all()
+        assert np.abs(a["sample"] - c["sample"]).max() < 1e-12
+        # the twins of the first 25 Gaussians are invisible
+        assert np.abs(a["sample"] - d["sample"]).max() < 1e-12
+        # (the NumPy one-pass form keeps depth + 1 entries: it may stop one short behind a twin,
+        # and says so through `fragile`)
+        short = b["hits"] != a["hits"]
+        assert (b["fragile"] | ~short).all()
+
+
 def test_fp32_literal_arithmetic_stays_near_the_fp64_golden():
     # the reference computes in fp32 (Taichi default_fp); its own arithmetic, restated literally,
     # is within ~1e-3 of the fp64 golden on the bounded-anisotropy scenes and mostly within 1e-4
@@ -131,6 +180,16 @@ def test_golden_fixtures_are_reproduced(name):
     assert (r["hits"] == g["hits"][sel]).all() and (r["fragile"] == g["fragile"][sel]).all()
     c = c_oracle.render(arrays, cam, depth, g["pixels"])
     assert np.abs(c["sample"] - g["sample"]).max() < 1e-9
+
+
+def test_c5_golden_sample_is_reproduced_by_the_c_oracle():
+    # 1 M Gaussians + SH: 48 pixels keep this under ten seconds on 8 cores
+    g = np.load(os.path.join(GOLDEN, "c5_crop.npz"))
+    arrays, cam, depth = scenes.config_case("c5")
+    sel = np.arange(0, g["pixels"].shape[0], 70)
+    c = c_oracle.render(arrays, cam, depth, g["pixels"][sel])
+    assert np.array_equal(c["sample"], g["sample"][sel])
+    assert (c["hits"] == g["hits"][sel]).all() and (c["fragile"] == g["fragile"][sel]).all()
 
 
 def test_c3_golden_sample_is_reproduced_by_the_c_oracle():
