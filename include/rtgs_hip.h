@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RTGS_ABI_VERSION 2
+#define RTGS_ABI_VERSION 3
 #define RTGS_MAX_DEPTH 16        /* peels kept per ray in one pass (__main__.py:70 default) */
 #ifndef RTGS_TILE
 #define RTGS_TILE 16             /* macro-tile edge in pixels: one workgroup, the unit of sharding */
@@ -70,6 +70,13 @@ typedef struct RtgsCamera {
   float rotation[4];          /* xyzw */
   int32_t width, height;      /* buf_size; sensor size == buf_size (camera.py:26) */
   float fx, fy;               /* focal_length, in pixels */
+  const void* device_pose;    /* NULL, or a DEVICE buffer of rtgs_pose_bytes() bytes holding what
+                                 rtgs_pose_pack() made of (position, rotation, fx, fy, width, height):
+                                 the kernels then read the pose from there instead of from this
+                                 struct, so that a captured hipGraph of rtgs_project + rtgs_trace can be
+                                 replayed with a new pose per frame (copy the packed block in from
+                                 pinned host memory inside the graph).  width/height/fx/fy of this
+                                 struct must still be the real ones: they size the launch. */
 } RtgsCamera;
 
 /* flags for RtgsTraceParams.flags */
@@ -116,6 +123,13 @@ int rtgs_precompute(int32_t n, const float* position /*[n][3]*/, const float* ro
 
 /* Camera.generate_ray_field (camera.py:57-71): rays[(i*H + j)*8 ..] = {o, d, 0, +inf}. */
 int rtgs_generate_rays(const RtgsCamera* cam, float* rays /*[W][H][8]*/, rtgs_stream_t stream);
+
+/* Camera pose block for RtgsCamera.device_pose: its size, and the packing of a camera into a HOST
+ * buffer of that size (plain host function: no device work).  The viewer loop of the reference
+ * re-generates its ray field from a new pose every frame (__main__.py:236-250, camera.py:57-71);
+ * this is that pose on a path that needs no new kernel arguments. */
+size_t rtgs_pose_bytes(void);
+int rtgs_pose_pack(const RtgsCamera* cam, void* host_out);
 
 /* Bytes of scratch rtgs_trace needs for n Gaussians (per-frame projected records). */
 size_t rtgs_workspace_bytes(int32_t n);

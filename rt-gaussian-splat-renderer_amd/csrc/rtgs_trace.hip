@@ -38,6 +38,8 @@
 //     on this path.
 #include "rtgs_common.hpp"
 
+#include <string.h>
+
 namespace rtgs {
 namespace {
 
@@ -154,6 +156,7 @@ struct TraceArgs {
   int32_t start_stride;
   const int32_t* tile_order;
   int32_t idx_bits;   // kSplit == 2: list entries carry (arrival rank << idx_bits) | index
+  const FrameCam* pose;   // optional: camera pose in device memory (only its rotation is used here)
 };
 
 // ------------------------------------------------------------------------------------
@@ -163,6 +166,7 @@ struct TraceArgs {
 __global__ __launch_bounds__(256) void k_project(int32_t n, const float* __restrict__ pos,
                                                   const float* __restrict__ rot,
                                                   const float* __restrict__ scale, FrameCam cam,
+                                                  const FrameCam* __restrict__ pose,
                                                   float4* __restrict__ bbox,
                                                   float4* __restrict__ slab_bbox,
                                                   float* __restrict__ slab_key,
@@ -178,6 +182,7 @@ __global__ __launch_bounds__(256) void k_project(int32_t n, const float* __restr
 #pragma unroll
   for (int k = 0; k < kTailFloats; ++k) tl[k] = 0.f;
 
+  if (pose) cam = *pose;   // camera pose from device memory (RtgsCamera.device_pose): wave-uniform loads
   const double mx = cam.o[0] - (double)pos[3 * g + 0];
   const double my = cam.o[1] - (double)pos[3 * g + 1];
   const double mz = cam.o[2] - (double)pos[3 * g + 2];
@@ -1009,9 +1014,12 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   if (kHasSh) {
     const float il = 1.0f / dlen;
     const float cx = dcx * il, cy = dcy * il, cz = -il;
-    float wx = a.rc[0] * cx + a.rc[1] * cy + a.rc[2] * cz;
-    float wy = a.rc[3] * cx + a.rc[4] * cy + a.rc[5] * cz;
-    float wz = a.rc[6] * cx + a.rc[7] * cy + a.rc[8] * cz;
+    float rcf[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) rcf[k] = a.pose ? (float)a.pose->rc[k] : a.rc[k];
+    float wx = rcf[0] * cx + rcf[1] * cy + rcf[2] * cz;
+    float wy = rcf[3] * cx + rcf[4] * cy + rcf[5] * cz;
+    float wz = rcf[6] * cx + rcf[7] * cy + rcf[8] * cz;
     const float in = 1.0f / sqrtf(wx * wx + wy * wy + wz * wz);  // gaussian.py:200
     sh_basis(wx * in, wy * in, wz * in, Ysh);
   }
@@ -1142,6 +1150,16 @@ size_t rtgs_workspace_bytes(int32_t n) {
          ((nslabs + 3) & ~(size_t)3) * sizeof(float);
 }
 
+size_t rtgs_pose_bytes(void) { return sizeof(FrameCam); }
+
+int rtgs_pose_pack(const RtgsCamera* cam, void* host_out) {
+  if (!cam || !host_out || cam->width <= 0 || cam->height <= 0 || !(cam->fx > 0.f) || !(cam->fy > 0.f))
+    return RTGS_EINVAL;
+  const FrameCam fc = make_frame_cam(*cam);
+  memcpy(host_out, &fc, sizeof(fc));
+  return RTGS_OK;
+}
+
 int32_t rtgs_tile_size(void) { return kTile; }
 
 int32_t rtgs_num_tiles(int32_t width, int32_t height) {
@@ -1183,7 +1201,8 @@ int rtgs_project(const RtgsScene* scene, const RtgsCamera* cam, void* workspace,
   const int block = 256;
   hipLaunchKernelGGL(k_project, dim3((scene->n + block - 1) / block), dim3(block), 0,
                      static_cast<hipStream_t>(stream), scene->n, scene->position, scene->rotation,
-                     scene->scale, fc, bbox, slab_bbox, slab_key_of(slab_bbox, nn), rec, tail);
+                     scene->scale, fc, static_cast<const FrameCam*>(cam->device_pose), bbox, slab_bbox,
+                     slab_key_of(slab_bbox, nn), rec, tail);
   const int nslabs = (int)(nn / kSlab);
   if (nslabs > kBigSceneSlabs || RTGS_TWO_LEVEL) {
     const int nsuper = (nslabs + kSuper - 1) / kSuper;
@@ -1228,6 +1247,7 @@ static int trace_impl(const RtgsScene* scene, const RtgsCamera* cam, const RtgsT
   a.inv_fx = (float)fc.inv_fx;
   a.inv_fy = (float)fc.inv_fy;
   for (int k = 0; k < 9; ++k) a.rc[k] = (float)fc.rc[k];
+  a.pose = static_cast<const FrameCam*>(cam->device_pose);
   const float4* bbox = static_cast<const float4*>(workspace);
   const float4* rec = bbox + nn;
   const float4* tail = rec + nn * (kRecFloats / 4);

@@ -14,7 +14,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_size_t, c_u
 
 import torch  # noqa: F401  (must precede the CDLL load, see module docstring)
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_DEPTH = 16
 RAY_FLOATS = 8
 SH_COEFFS = 15
@@ -36,7 +36,7 @@ class RtgsScene(Structure):
 
 class RtgsCamera(Structure):
     _fields_ = [("position", c_float * 3), ("rotation", c_float * 4), ("width", c_int32),
-                ("height", c_int32), ("fx", c_float), ("fy", c_float)]
+                ("height", c_int32), ("fx", c_float), ("fy", c_float), ("device_pose", c_void_p)]
 
 
 class RtgsTraceParams(Structure):
@@ -51,6 +51,8 @@ PROTOTYPES = {
     "rtgs_covariance": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rtgs_generate_rays": (c_int32, [POINTER(RtgsCamera), c_void_p, c_void_p]),
     "rtgs_workspace_bytes": (c_size_t, [c_int32]),
+    "rtgs_pose_bytes": (c_size_t, []),
+    "rtgs_pose_pack": (c_int32, [POINTER(RtgsCamera), c_void_p]),
     "rtgs_tile_size": (c_int32, []),
     "rtgs_num_tiles": (c_int32, [c_int32, c_int32]),
     "rtgs_num_local_tiles": (c_int32, [c_int32, c_int32, c_int32, c_int32]),
@@ -144,8 +146,9 @@ def device() -> torch.device:
     return torch.device("cuda", torch.cuda.current_device())
 
 
-def make_camera(position, rotation, width, height, fx, fy) -> RtgsCamera:
+def make_camera(position, rotation, width, height, fx, fy, device_pose=None) -> RtgsCamera:
     c = RtgsCamera()
+    c.device_pose = device_pose
     for k in range(3):
         c.position[k] = float(position[k])
     for k in range(4):

@@ -30,11 +30,11 @@ class Camera:
         self.field_rotation = vec4(rotation)
         self.cam_ray_field.mark_edited(False)
 
-    def native(self, position=None, rotation=None) -> nat.RtgsCamera:
+    def native(self, position=None, rotation=None, device_pose=None) -> nat.RtgsCamera:
         return nat.make_camera(self.position if position is None else position,
                                self.rotation if rotation is None else rotation,
                                self.buf_size.x, self.buf_size.y, self.focal_length.x,
-                               self.focal_length.y)
+                               self.focal_length.y, device_pose)
 
     def generate_ray(self, position, rotation, uv) -> Ray:
         """One camera ray through screen coordinate uv in [0,1]^2, (0,0) bottom-left

@@ -58,6 +58,12 @@ class HipBackend:
         need = nat.lib().rtgs_workspace_bytes(scene.num_gaussians)
         self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
         self._orders = {}
+        # Optional hipGraph replay of project + trace (RTGS_GRAPH=1).  OFF by default: measured on
+        # MI355X / ROCm 7.2 (tools/graph_vs_direct.py) a replay costs 12 us more per frame than the
+        # two direct launches and holds the host until the graph has run (c3 1/8 shard: 70.9 vs
+        # 58.1 us per frame; direct launches cost the host 13.5 us and overlap the GPU)
+        self.use_graph = os.environ.get("RTGS_GRAPH", "0") == "1"
+        self._graphs = {}
 
     def tile_order(self, tile_first: int, tile_step: int):
         key = (tile_first, tile_step)
@@ -91,10 +97,76 @@ class HipBackend:
                                        self.workspace.numel(), 1 if projected else 0, nat.stream()),
                   "rtgs_trace")
 
+    # ---- hipGraph path ---------------------------------------------------------------------
+    def frame_graph(self, out, tile_first: int, tile_step: int, compact: bool):
+        """A captured hipGraph of [pose upload, rtgs_project, rtgs_trace] writing into `out`.  The
+        camera pose travels through a device block (RtgsCamera.device_pose) that the graph refreshes
+        from pinned host memory, so a replay renders the pose packed just before it."""
+        key = (out.data_ptr(), tile_first, tile_step, compact)
+        g = self._graphs.get(key)
+        if g is None:
+            g = _FrameGraph(self, out, tile_first, tile_step, compact)
+            self._graphs[key] = g
+        return g
+
+    def render(self, out, tile_first: int, tile_step: int, compact: bool):
+        """project + trace of one shard into `out` on the current stream: graph replay, or two
+        direct launches when graphs are disabled (RTGS_GRAPH=0)."""
+        if self.use_graph:
+            self.frame_graph(out, tile_first, tile_step, compact).replay()
+        else:
+            self.trace(out, tile_first, tile_step, compact)
+
     def untile(self, gathered, world: int, tiles_per_rank: int, image):
         nat = self.nat
         nat.check(nat.lib().rtgs_untile(nat.ptr(gathered), world, tiles_per_rank, self.width,
                                         self.height, nat.ptr(image), nat.stream()), "rtgs_untile")
+
+
+class _FrameGraph:
+    """One captured frame of one shard (see HipBackend.frame_graph): the graph holds rtgs_project +
+    rtgs_trace; the pose block they read is refreshed before every replay by one async copy from a
+    small ring of pinned host blocks, so the host never waits for the GPU."""
+
+    RING = 4
+
+    def __init__(self, backend: HipBackend, out, tile_first, tile_step, compact):
+        nat = backend.nat
+        self.b = backend
+        nbytes = nat.lib().rtgs_pose_bytes()
+        self.pose_host = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(self.RING)]
+        self.copied = [torch.cuda.Event() for _ in range(self.RING)]   # the copy out of block k is done
+        self.pose_dev = torch.empty(nbytes, dtype=torch.uint8, device=backend.device)
+        self.turn = 0
+        self._upload()
+        order = backend.tile_order(tile_first, tile_step) if backend.use_tile_order else None
+        flags = nat.TRACE_COMPACT if compact else 0
+        params = nat.RtgsTraceParams(backend.depth, backend.t_cutoff, tile_first, tile_step, flags, nat.ptr(order))
+        scene = backend.scene.native()
+        self.scene_version = backend.scene.version
+        ncam = backend.camera.native(device_pose=self.pose_dev.data_ptr())
+        self.graph = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(self.graph):
+            nat.check(nat.lib().rtgs_trace(scene, ncam, params, nat.ptr(out), None, None, 1,
+                                           nat.ptr(backend.workspace), backend.workspace.numel(), 0,
+                                           nat.stream()), "rtgs_trace (capture)")
+        self._keep = (order, params, scene, ncam)
+
+    def _upload(self):
+        nat = self.b.nat
+        k = self.turn % self.RING
+        self.turn += 1
+        self.copied[k].synchronize()        # RING frames old: long complete
+        nat.check(nat.lib().rtgs_pose_pack(self.b.camera.native(), self.pose_host[k].data_ptr()), "rtgs_pose_pack")
+        self.pose_dev.copy_(self.pose_host[k], non_blocking=True)
+        self.copied[k].record()
+
+    def replay(self):
+        if self.scene_version != self.b.scene.version:
+            raise RuntimeError("the scene was re-committed after this frame graph was captured")
+        self._upload()
+        self.graph.replay()
 
 
 class TileParallelRenderer:
@@ -125,12 +197,12 @@ class TileParallelRenderer:
         rank's tiles, start the gather, then complete the previous frame (double buffering)."""
         b = self.backend
         if self.world == 1:
-            b.trace(self.framebuffer, 0, 1, compact=False)
+            b.render(self.framebuffer, 0, 1, compact=False)
             return
         k = self._frame & 1
         self._frame += 1
         if self.local_tiles:
-            b.trace(self.compact[k], self.rank, self.world, compact=True)
+            b.render(self.compact[k], self.rank, self.world, compact=True)
         glist = list(self.gathered[k].unbind(0)) if self.rank == self.dst else None
         work = self._gather(self.compact[k], gather_list=glist, dst=self.dst, group=self.group,
                             async_op=True)

@@ -569,6 +569,42 @@ def test_tile_parallel_frame_loop_end_to_end(world):
     assert all(r.framebuffer is None for r in ranks[1:])
 
 
+def test_frame_graph_replays_with_new_poses():
+    # one captured hipGraph of [pose upload, rtgs_project, rtgs_trace] per shard; the pose travels
+    # through RtgsCamera.device_pose, so replays follow a moving camera (position AND rotation, SH
+    # direction included) and equal direct launches bit for bit
+    from rtgs.parallel import HipBackend
+    from rtgs.utils.types import vec3, vec4
+    arrays, cam, depth = U.case("sh")
+    scene, camera, tracer = U.build(arrays, cam)
+    b = HipBackend(scene, camera, depth)
+    b.use_graph = True          # opt-in (RTGS_GRAPH=1): see HipBackend.__init__ for the measurement
+    w, h = cam["width"], cam["height"]
+    whole = b.alloc(w, h, 3)
+    T = nat.tile_size()
+    per = (nat.lib().rtgs_num_tiles(w, h) + 2) // 3
+    shard = b.alloc(per, T, T, 3)
+    poses = [(cam["position"], cam["rotation"]), ((0.9, -0.2, 2.4), scenes.quat_axis_angle((0.1, 1.0, 0.0), -0.3)),
+             ((-0.4, 0.3, 3.3), scenes.quat_axis_angle((1.0, 0.2, 0.1), 0.2)), (cam["position"], cam["rotation"])]
+    prev = None
+    for pos, rot in poses:
+        camera.position, camera.rotation = vec3(pos), vec4(rot)
+        b.render(whole, 0, 1, compact=False)
+        b.render(shard, 1, 3, compact=True)
+        tracer.trace(depth)
+        want_shard = torch.zeros_like(shard)
+        tracer.trace(depth, flags=nat.TRACE_COMPACT, tile_first=1, tile_step=3, sample_buf=want_shard)
+        torch.cuda.synchronize()
+        assert torch.equal(whole, tracer.sample_buf) and torch.equal(shard, want_shard)
+        if prev is not None and pos != poses[0][0]:
+            assert float((whole - prev).abs().max()) > 1e-2
+        prev = whole.clone()
+    assert len(b._graphs) == 2          # captured once per (buffer, shard), replayed afterwards
+    scene.commit()
+    with pytest.raises(RuntimeError, match="re-committed"):
+        b.render(whole, 0, 1, compact=False)
+
+
 def test_single_peel_calls_reuse_the_projection_and_track_scene_changes():
     # sample() x depth projects once (camera unchanged) yet must notice a new camera pose or a
     # re-committed scene

@@ -57,6 +57,9 @@ class OracleBackend:
             blk = img[i0:i0 + TILE, j0:j0 + TILE]
             out[local, :blk.shape[0], :blk.shape[1]] = blk
 
+    def render(self, out, tile_first, tile_step, compact):
+        self.trace(out, tile_first, tile_step, compact)
+
     def untile(self, gathered, world, tiles_per_rank, image):
         tx = (W + TILE - 1) // TILE
         for t in range(tx * ((H + TILE - 1) // TILE)):
