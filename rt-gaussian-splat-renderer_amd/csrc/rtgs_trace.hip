@@ -72,6 +72,9 @@ namespace {
 #define RTGS_LOOKAHEAD 1  // big scenes: touch the next candidate's record line one iteration ahead (scalar-cache
 #endif                    // prefetch).  c5 (64 MB of records) 1.74 -> 1.58 ms; c3 (6.4 MB, L2-resident) 0.188 -> 0.192: off there
 
+#ifndef RTGS_HORIZON
+#define RTGS_HORIZON 1    // chunk-level horizon test against the per-Gaussian distance bound (see k_trace)
+#endif
 #ifndef RTGS_TIER
 #define RTGS_TIER 8       // insertions touch only the first RTGS_TIER slots while slot RTGS_TIER-1 is empty in every lane (0: off)
 #endif
@@ -84,6 +87,18 @@ namespace {
 #endif
 #ifndef RTGS_GROUP
 #define RTGS_GROUP 4
+#endif
+#ifndef RTGS_SLAB_ITERS_BIG
+#define RTGS_SLAB_ITERS_BIG 4
+#endif
+#ifndef RTGS_SLAB_CAP_BIG
+#define RTGS_SLAB_CAP_BIG 2048
+#endif
+#ifndef RTGS_SLABS_PER_WAVE_BIG
+#define RTGS_SLABS_PER_WAVE_BIG 4
+#endif
+#ifndef RTGS_GROUP_BIG
+#define RTGS_GROUP_BIG 4   // c5: 1.53 ms vs 1.67 with 8 (register pressure of the SH variant), 1.54 with 2
 #endif
 #ifndef RTGS_SLAB_CAP
 #define RTGS_SLAB_CAP 768
@@ -100,14 +115,14 @@ template <bool kBig, int kSplit = 1>
 struct Tune {
   static constexpr int kWaves = kWavesPerTile * kSplit;     // waves per workgroup
   static constexpr int kBlock = kWaves * kWave;             // threads per workgroup
-  static constexpr int kSlabIters = (kBig ? 4 : RTGS_SLAB_ITERS) / kSplit;  // slab bounds in flight per thread
+  static constexpr int kSlabIters = (kBig ? RTGS_SLAB_ITERS_BIG : RTGS_SLAB_ITERS) / kSplit;  // slab bounds in flight per thread
   static constexpr int kSlabStep = kSlabIters * kBlock;     // slabs scanned per barrier
-  static constexpr int kSlabCap = kBig ? 2048 : RTGS_SLAB_CAP;   // LDS list of surviving slabs
-  static constexpr int kSlabsPerWave = kBig ? 4 : RTGS_SLABS_PER_WAVE;   // slabs one wave expands per batch
+  static constexpr int kSlabCap = kBig ? RTGS_SLAB_CAP_BIG : RTGS_SLAB_CAP;   // LDS list of surviving slabs
+  static constexpr int kSlabsPerWave = kBig ? RTGS_SLABS_PER_WAVE_BIG : RTGS_SLABS_PER_WAVE;   // slabs one wave expands per batch
   // LDS list of surviving Gaussians (indices): kWavesPerTile regions of kSlabsPerWave slabs' worth;
   // the same in both workgroup forms, so that both see the same list order
   static constexpr int kListCap = kSlabsPerWave * kWavesPerTile * kSlab;
-  static constexpr int kGroup = kBig ? 8 : RTGS_GROUP;       // colour/opacity gathers in flight
+  static constexpr int kGroup = kBig ? RTGS_GROUP_BIG : RTGS_GROUP;   // colour/opacity gathers in flight
   static_assert(kSlabCap >= kSlabStep + 64, "slab list too small");
 };
 #ifndef RTGS_BIG_SLABS
@@ -170,7 +185,8 @@ __global__ __launch_bounds__(256) void k_project(int32_t n, const float* __restr
                                                   float4* __restrict__ bbox,
                                                   float4* __restrict__ slab_bbox,
                                                   float* __restrict__ slab_key,
-                                                  float* __restrict__ rec, float* __restrict__ tail) {
+                                                  float* __restrict__ rec, float* __restrict__ tail,
+                                                  float* __restrict__ tmin) {
   const int g0 = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = g0 < n;
   const int g = live ? g0 : n - 1;   // padding lanes recompute the last record, store nothing
@@ -367,6 +383,16 @@ __global__ __launch_bounds__(256) void k_project(int32_t n, const float* __restr
     }
   }
   if (live) {
+    // lower bound of the entry distance t1 over ALL rays: the ellipsoid {d^T Sigma^-1 d <= 3} lies in
+    // the ball of radius sqrt(3) |q|^2 s_max about the centre.  k_trace's horizon test skips a
+    // candidate whose bound is beyond the 16th entry of every ray of the tile.
+    {
+      const double k2 = (double)rot[4 * g] * rot[4 * g] + (double)rot[4 * g + 1] * rot[4 * g + 1] +
+                        (double)rot[4 * g + 2] * rot[4 * g + 2] + (double)rot[4 * g + 3] * rot[4 * g + 3];
+      const double smax = fmax(fabs((double)scale[3 * g]), fmax(fabs((double)scale[3 * g + 1]), fabs((double)scale[3 * g + 2])));
+      const double lo = sqrt(mx * mx + my * my + mz * mz) - 1.7320508075688774 * k2 * smax;
+      tmin[g] = lo > 0.0 ? (float)(lo * (1.0 - 1e-6)) : 0.f;   // NaN -> 0: never skipped
+    }
     bbox[g] = bb;
     float4* out = reinterpret_cast<float4*>(rec + (size_t)g * kRecFloats);
 #pragma unroll
@@ -520,6 +546,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
                                                           const float4* __restrict__ super_bbox,
                                                           const float4* __restrict__ rec,
                                                           const float4* __restrict__ tail,
+                                                          const float* __restrict__ tmin,
                                                           const float4* __restrict__ colop,
                                                           const float* __restrict__ sh) {
   static_assert(kSplit == 1 || kSplit == 2, "one or two waves per 8x8 tile");
@@ -605,6 +632,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
 #pragma unroll
   for (int k = 0; k < kWn; ++k) wexp[k] = 0.f;
   [[maybe_unused]] float* const s_wl = s_w + tid;
+  constexpr bool kHorizon = RTGS_HORIZON != 0 && kK == RTGS_MAX_DEPTH;
   constexpr bool kLookahead = RTGS_LOOKAHEAD == 2 || (RTGS_LOOKAHEAD == 1 && kBig);
   constexpr int kTier = (kLdsW && RTGS_TIER > 0 && RTGS_TIER < kK) ? RTGS_TIER : kK;
   [[maybe_unused]] bool tier_short = kTier < kK;   // wave-uniform: slot kTier-1 still empty in every lane
@@ -791,9 +819,10 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
 #endif
       // ---- every wave: survivors vs its own 8x8 tile, then exact per-ray tests.  The regions
       // are walked as one list; the next chunk's bounds load while this chunk's candidates run.
-      auto fetch = [&](int c, int& g, float4& wb) {
+      auto fetch = [&](int c, int& g, float4& wb, float& tm) {
         const int v = c + lane;
         g = -1;
+        tm = 0.f;
         wb = make_float4(kInf, kInf, -kInf, -kInf);
         if (v < total) {
           int slot = v, base = 0;
@@ -804,14 +833,16 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
           }
           g = s_idx[slot];
           wb = bbox[g];
+          if constexpr (kHorizon) tm = tmin[g];
         }
       };
       if (wave_live && total > 0) {
         int g, gnext = -1;
         float4 wb, wbnext = make_float4(kInf, kInf, -kInf, -kInf);
-        fetch(0, g, wb);
+        float tm, tmnext = 0.f;
+        fetch(0, g, wb, tm);
         for (int c = 0; c < total; c += kWave) {
-          if (c + kWave < total) fetch(c + kWave, gnext, wbnext);
+          if (c + kWave < total) fetch(c + kWave, gnext, wbnext, tmnext);
           const bool pass = wb.x <= wXhi && wb.z >= wXlo && wb.y <= wYhi && wb.w >= wYlo;
           unsigned long long m = __ballot(pass);
           [[maybe_unused]] const unsigned long long m_all = m;
@@ -825,6 +856,21 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
             const bool odd_first = ((turn ^ role) & 1) == 0;   // this wave takes the 1st, 3rd, ...
             turn += __popcll(m);
             m &= odd_first ? par_m : ~par_m;
+          }
+          if constexpr (kHorizon) {
+            // Horizon: once every ray of the tile holds kK entries, a candidate whose distance bound
+            // lies at or beyond the farthest of their last entries cannot enter any list.  One wave
+            // reduction per 64 candidates; the image does not depend on it (such a candidate would
+            // fail `kn < key[kK-1]` in every lane).  Scenes with large background Gaussians
+            // (capture-like, tools/cap_sweep.py) lose most of their candidates here.
+            unsigned h = in_img ? key[kK - 1] : 0u;       // t1 bits; +inf while the list is not full
+            h = max(h, (unsigned)__builtin_amdgcn_update_dpp(0, (int)h, 0xB1, 0xF, 0xF, false));    // quad_perm 1,0,3,2
+            h = max(h, (unsigned)__builtin_amdgcn_update_dpp(0, (int)h, 0x4E, 0xF, 0xF, false));    // quad_perm 2,3,0,1
+            h = max(h, (unsigned)__builtin_amdgcn_update_dpp(0, (int)h, 0x141, 0xF, 0xF, false));   // row_half_mirror
+            h = max(h, (unsigned)__builtin_amdgcn_update_dpp(0, (int)h, 0x140, 0xF, 0xF, false));   // row_mirror
+            const unsigned hz = max(max((unsigned)__builtin_amdgcn_readlane((int)h, 0), (unsigned)__builtin_amdgcn_readlane((int)h, 16)),
+                                    max((unsigned)__builtin_amdgcn_readlane((int)h, 32), (unsigned)__builtin_amdgcn_readlane((int)h, 48)));
+            if (hz < kEmpty) m &= __ballot(tm < __uint_as_float(hz));
           }
 #if RTGS_ABLATE >= 3
           asm volatile("" ::"s"(m));
@@ -949,6 +995,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
           }
           g = gnext;
           wb = wbnext;
+          tm = tmnext;
         }
       }
       __syncthreads();  // everyone is done with the list before the next round (or the next scan) refills it
@@ -1146,7 +1193,7 @@ size_t rtgs_workspace_bytes(int32_t n) {
   if (n <= 0) return 0;
   const size_t nn = ((size_t)n + 63) & ~(size_t)63;
   const size_t nslabs = nn / kSlab, nsuper = (nslabs + kSuper - 1) / kSuper;
-  return nn * sizeof(float4) + nn * (kRecFloats + kTailFloats) * sizeof(float) + (nslabs + nsuper) * sizeof(float4) +
+  return nn * sizeof(float4) + nn * (kRecFloats + kTailFloats + 1) * sizeof(float) + (nslabs + nsuper) * sizeof(float4) +
          ((nslabs + 3) & ~(size_t)3) * sizeof(float);
 }
 
@@ -1173,7 +1220,7 @@ int32_t rtgs_num_local_tiles(int32_t width, int32_t height, int32_t tile_first, 
   return (total - tile_first + tile_step - 1) / tile_step;
 }
 
-// workspace: [bbox nn x float4][records nn x 16 float][tails nn x 8 float][slab bounds][group bounds][slab depth keys]
+// workspace: [bbox nn x float4][records nn x 16 float][tails nn x 8 float][distance bounds nn float][slab bounds][group bounds][slab depth keys]
 static float* slab_key_of(float4* slab_bbox, size_t nn) {
   const size_t nslabs = nn / kSlab, nsuper = (nslabs + kSuper - 1) / kSuper;
   return reinterpret_cast<float*>(slab_bbox + nslabs + nsuper);
@@ -1196,13 +1243,14 @@ int rtgs_project(const RtgsScene* scene, const RtgsCamera* cam, void* workspace,
   float4* bbox = static_cast<float4*>(workspace);
   float* rec = reinterpret_cast<float*>(bbox + nn);
   float* tail = rec + nn * kRecFloats;
-  float4* slab_bbox = reinterpret_cast<float4*>(tail + nn * kTailFloats);
+  float* tmin = tail + nn * kTailFloats;
+  float4* slab_bbox = reinterpret_cast<float4*>(tmin + nn);
   const FrameCam fc = make_frame_cam(*cam);
   const int block = 256;
   hipLaunchKernelGGL(k_project, dim3((scene->n + block - 1) / block), dim3(block), 0,
                      static_cast<hipStream_t>(stream), scene->n, scene->position, scene->rotation,
                      scene->scale, fc, static_cast<const FrameCam*>(cam->device_pose), bbox, slab_bbox,
-                     slab_key_of(slab_bbox, nn), rec, tail);
+                     slab_key_of(slab_bbox, nn), rec, tail, tmin);
   const int nslabs = (int)(nn / kSlab);
   if (nslabs > kBigSceneSlabs || RTGS_TWO_LEVEL) {
     const int nsuper = (nslabs + kSuper - 1) / kSuper;
@@ -1251,7 +1299,8 @@ static int trace_impl(const RtgsScene* scene, const RtgsCamera* cam, const RtgsT
   const float4* bbox = static_cast<const float4*>(workspace);
   const float4* rec = bbox + nn;
   const float4* tail = rec + nn * (kRecFloats / 4);
-  const float4* slab_bbox = tail + nn * (kTailFloats / 4);
+  const float* tmin = reinterpret_cast<const float*>(tail + nn * (kTailFloats / 4));
+  const float4* slab_bbox = reinterpret_cast<const float4*>(tmin + nn);
   const float4* super_bbox = slab_bbox + nn / kSlab;
   const float4* colop = reinterpret_cast<const float4*>(scene->color_opacity);
   a.sample = sample_buf;
@@ -1273,7 +1322,7 @@ static int trace_impl(const RtgsScene* scene, const RtgsCamera* cam, const RtgsT
   if (params->depth == 1) split = false;
 #define RTGS_LAUNCH(HAS_SH, BIG, K, SPLIT)                                                         \
   hipLaunchKernelGGL((k_trace<HAS_SH, BIG, K, SPLIT>), dim3(local), dim3(kTraceBlock * SPLIT), 0, s, a, \
-                     bbox, slab_bbox, super_bbox, rec, tail, colop, sh)
+                     bbox, slab_bbox, super_bbox, rec, tail, tmin, colop, sh)
 #define RTGS_LAUNCH_K(HAS_SH, BIG)                                                  \
   do {                                                                              \
     if (params->depth == 1) RTGS_LAUNCH(HAS_SH, BIG, 1, 1);                         \

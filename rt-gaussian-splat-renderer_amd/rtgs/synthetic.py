@@ -37,6 +37,8 @@ CONFIGS = {
     "c3": Config("c3", 100_000, 1920, 1080, 1003),
     "c4": Config("c4", 100_000, 1920, 1080, 1003),       # c3 sharded over 8 GPUs
     "c5": Config("c5", 1_000_000, 3840, 2160, 1005, sh=True),
+    # not a BASELINE config: c3's size with capture-like statistics, see make_capture_scene
+    "cap": Config("cap", 100_000, 1920, 1080, 1013),
 }
 
 
@@ -71,9 +73,37 @@ def make_scene(n: int, aspect: float, seed: int, sh: bool = False) -> dict:
             for k, v in out.items()}
 
 
+def make_capture_scene(n: int, aspect: float, seed: int, sigma: float = 1.2, background: float = 0.01) -> dict:
+    """A scene with the size statistics of a captured 3DGS model (the reference's use case is
+    truck.ply, ~150 k Gaussians: docs/source/get-started.md:64-74) instead of c3's 4:1 spread:
+    per-Gaussian size log-normal (sigma in ln s), per-axis anisotropy on top, and `background`
+    (1 %) of the Gaussians large (6 x s0), faint and in the back third of the box.  The median
+    size is chosen so that the log-normal part covers the screen as c3 does (E[s^2] = s0^2).
+    Only rng.random() is used (Box-Muller for the normals)."""
+    rng = np.random.default_rng(seed)
+    base = make_scene(n, aspect, seed)
+    u = rng.random((n, 2))
+    z = np.sqrt(-2.0 * np.log(1.0 - u[:, 0])) * np.cos(2.0 * math.pi * u[:, 1])     # N(0, 1)
+    s0 = math.sqrt(8.727 * aspect / n)
+    size = s0 * math.exp(-sigma * sigma) * np.exp(sigma * z)                          # median s0 e^{-sigma^2}
+    scale = size[:, None] * np.exp2(rng.random((n, 3)) * 2.0 - 1.0)
+    pos = base["position"].astype(np.float64)
+    opacity = base["opacity"].astype(np.float64)
+    nb = int(round(n * background))
+    if nb:
+        pick = rng.random(n).argsort()[:nb]
+        scale[pick] = 6.0 * s0 * np.exp2(rng.random((nb, 3)) - 0.5)
+        pos[pick, 2] = -1.0 + (2.0 / 3.0) * rng.random(nb)
+        opacity[pick] = 0.05 + 0.25 * rng.random(nb)
+    out = dict(base, position=pos, scale=scale, opacity=opacity)
+    return {k: (None if v is None else np.ascontiguousarray(v, dtype=np.float32)) for k, v in out.items()}
+
+
 def make_config_scene(cfg: Config | str) -> dict:
     if isinstance(cfg, str):
         cfg = CONFIGS[cfg]
+    if cfg.name == "cap":
+        return make_capture_scene(cfg.n, cfg.aspect, cfg.seed)
     return make_scene(cfg.n, cfg.aspect, cfg.seed, cfg.sh)
 
 

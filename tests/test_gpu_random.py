@@ -172,6 +172,7 @@ def test_fuzz_sweep():
     # 1x1, slab-boundary Gaussian counts, needles, cameras inside the cloud, sharded launches and
     # the reference's one-peel-per-call pattern
     worst = 0.0
+    n_px = n_fragile = 0
     for seed in range(7000, 7080):
         arrays, cam, depth, world, mode = scenes.fuzz_case(seed)
         _, _, tr = U.build(arrays, cam)
@@ -190,4 +191,37 @@ def test_fuzz_sweep():
         e = float(err[solid].max()) if solid.any() else 0.0
         assert e <= U.PIXEL_TOL, f"seed {seed}: {e:.3e} ({cam['width']}x{cam['height']}, n={arrays['position'].shape[0]}, depth {depth}, world {world}, mode {mode})"
         worst = max(worst, e)
-    print(f"fuzz sweep: worst robust-pixel error {worst:.2e}")
+        # the excluded pixels are bounded in number (per case: tiny images of huge Gaussians reach
+        # 6 %; over the slice 0.06 %) and never garbage: within one contribution of the oracle
+        assert 1.0 - solid.mean() <= 0.08, f"seed {seed}: {1 - solid.mean():.2%} fragile"
+        if (~solid).any():
+            assert err[~solid].max() <= 0.9 * max(1.0, float(np.abs(want["sample"]).max())), seed
+        n_px += err.size
+        n_fragile += int((~solid).sum())
+    assert n_fragile <= U.MAX_FRAGILE_FRACTION * n_px
+    print(f"fuzz sweep: worst robust-pixel error {worst:.2e}; fragile {n_fragile} of {n_px} pixels")
+
+
+def test_capture_like_scene_matches_the_oracle():
+    # c3's size with the size statistics of a captured model (the reference's use
+    # case is truck.ply, docs/source/get-started.md:64-74): log-normal sizes over three decades,
+    # 1 % large faint background Gaussians.  Sampled pixels + a centre crop against the C oracle.
+    cfg = synthetic.CONFIGS["cap"]
+    arrays = synthetic.make_config_scene(cfg)
+    cam = synthetic.bench_camera(cfg.width, cfg.height)
+    assert arrays["scale"].max() / np.median(arrays["scale"]) > 30
+    _, _, tracer = U.build(arrays, cam)
+    tracer.sample_all(cfg.depth)
+    torch.cuda.synchronize()
+    pix = scenes.crop_pixels(cfg.width, cfg.height, 48, 27, seed=11, extra=3000)
+    want = c_oracle.render(arrays, cam, cfg.depth, pix)
+    worst = U.assert_parity(U.at(tracer.sample_buf, pix), want, "capture-like scene")
+    assert want["hits"].mean() > 6 and np.abs(U.at(tracer.attenuation_buf, pix) - want["attenuation"])[~want["fragile"]].max() <= U.PIXEL_TOL
+    # the same frame in 8 tile-interleaved shards and in the two-wave form
+    whole = tracer.sample_buf.clone()
+    from rtgs import _native as nat
+    tracer.clear_sample()
+    for r in range(8):
+        tracer.trace(cfg.depth, tile_first=r, tile_step=8, flags=nat.TRACE_SPLIT_ON if r % 2 else 0)
+    assert torch.equal(tracer.sample_buf, whole)
+    print(f"capture-like scene: max |err| {worst:.2e}, mean hits {want['hits'].mean():.1f}")

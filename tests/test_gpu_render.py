@@ -46,13 +46,18 @@ def test_golden_parity(name):
           f"{int((~solid).sum())} fragile")
 
 
-def test_fragile_pixels_stay_plausible():
+@pytest.mark.parametrize("name", ["c1_full", "c2_crop", "c3_crop", "c5_crop", "oblique_full", "inside_full",
+                                  "sh_full", "shallow_full"])
+def test_fragile_pixels_stay_plausible(name):
     # a fragile pixel may take the other branch of a discontinuity, never produce garbage:
-    # it must still be within one contribution (alpha <= opacity_max) of the golden
-    g = U.golden("c1_full")
-    tracer, _, _ = render_full("c1")
+    # it must still be within one contribution (alpha <= opacity_max = 0.9) of the golden
+    g = U.golden(name)
+    if not g["fragile"].any():
+        return
+    tracer, _, _ = render_full(name.split("_")[0])
     got = U.at(tracer.sample_buf, g["pixels"])
-    assert np.abs(got - g["sample"])[g["fragile"]].max() <= 0.9
+    bound = 0.9 * (1.0 + (0.45 if name.startswith(("c5", "sh")) else 0.0))   # SH adds up to ~0.45 to a colour
+    assert np.abs(got - g["sample"])[g["fragile"]].max() <= bound
 
 
 # ---- analytic single-Gaussian cases (same derivations as tests/test_oracle_analytic.py) ----
