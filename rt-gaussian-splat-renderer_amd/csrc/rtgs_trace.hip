@@ -97,6 +97,12 @@ namespace {
 #ifndef RTGS_SLABS_PER_WAVE_BIG
 #define RTGS_SLABS_PER_WAVE_BIG 4
 #endif
+#ifndef RTGS_EXPAND
+#define RTGS_EXPAND 1      // c3: 0.185 ms with 1, 0.189 with 2, 0.194 with 4 (registers); c5 does not care
+#endif
+#ifndef RTGS_EXPAND_BIG
+#define RTGS_EXPAND_BIG 4
+#endif
 #ifndef RTGS_GROUP_BIG
 #define RTGS_GROUP_BIG 4   // c5: 1.53 ms vs 1.67 with 8 (register pressure of the SH variant), 1.54 with 2
 #endif
@@ -145,15 +151,15 @@ constexpr int kSplitMaxTiles = RTGS_SPLIT_MAX_TILES;
 // is faster flat (one barrier less), so Tune<false> keeps the flat scan.
 constexpr int kSuper = RTGS_SUPER;
 // A tile's surviving slabs are visited nearest first (by k_project's depth key) when there are at
-// most kSortMax of them -- the same bound for every instantiation.  In stream (Morton) order near
+// most kSortMax of them (512 / 1024 for scenes above 262 k Gaussians: as many keys as fit the LDS
+// they borrow; both workgroup forms use the same bound).  In stream (Morton) order near
 // and far Gaussians interleave and nearly EVERY candidate inserts into some lane's list; nearest
 // first, the lists fill with near entries and far candidates are rejected wave-wide: 56 -> 44
 // inserting candidates on c3's central 8x8 tiles (simulated with the oracle; sorting single
 // Gaussians exactly would give 43.5).  Pixels do not depend on the order (see list_insert_par).
 #ifndef RTGS_SORT_MAX
-#define RTGS_SORT_MAX 256
+#define RTGS_SORT_MAX 4096   // capped by the LDS the depth keys can borrow: kListCap floats (512 / 1024)
 #endif
-constexpr int kSortMax = RTGS_SORT_MAX;
 
 struct TraceArgs {
   int32_t n;
@@ -568,12 +574,12 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   __shared__ int s_slab[kSlabCap];
   // depth keys of the first kSortMax listed slabs: only alive between the scan and the sort, when
   // the survivor pool is idle (every batch ends with a barrier) -- they share its LDS
-  static_assert(kPoolF4 * 4 >= kSortMax, "depth keys overlay the survivor pool");
+  constexpr int kSortMax = RTGS_SORT_MAX < kListCap ? RTGS_SORT_MAX : kListCap;   // kListCap floats fit the pool
   float* const s_skey = reinterpret_cast<float*>(s_pool);
   __shared__ int s_wcnt[2][kWaves];
   constexpr int kRegions = kWavesPerTile;            // expander waves = regions of the survivor list
   constexpr int kRegionCap = kListCap / kRegions;
-  constexpr int kExpand = kSlabsPerWave;             // slabs one wave has in flight
+  constexpr int kExpand = kBig ? RTGS_EXPAND_BIG : RTGS_EXPAND;   // slabs one wave has in flight
   static_assert(kRegionCap >= kSlab, "a region must hold one whole slab");
   __shared__ int s_rcnt[kRegions], s_rmore[kRegions];
   constexpr int kSuperStep = kSlabIters * kBlock;   // slab groups scanned per outer step
@@ -646,7 +652,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   const float* const slab_key = reinterpret_cast<const float*>(slab_bbox + nslabs + (nslabs + kSuper - 1) / kSuper);
 #if RTGS_STAMPS
   unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
-  int c_iter = 0, c_hit = 0, c_ins = 0;
+  int c_iter = 0, c_hit = 0, c_ins = 0, c_slabs = 0;
   unsigned long long t_ins = 0, t_loop0 = 0, t_front = 0;
   const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz: calibrates the shader clock
   st[0] = __builtin_amdgcn_s_memtime();
@@ -739,24 +745,34 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
     if (scnt + kSlabStep <= kSlabCap && !last) continue;
     __syncthreads();  // the slab list is complete
     if (kSortMax > 0 && scnt > 1 && scnt <= kSortMax) {
-      // nearest slabs first: rank by (key, list position), one listed slab per thread.  (One wave
-      // exchanging the keys by v_readlane instead of LDS, and skipping lists shorter than 8 or 16:
-      // all slower, 0.275-0.281 vs 0.270 ms on c3.)
-      int my_slab = 0, rank = 0;
-      if (tid < scnt) {
-        my_slab = s_slab[tid];
-        const float my_key = s_skey[tid];
-        for (int j = 0; j < scnt; ++j) {
-          const float kj = s_skey[j];
-          rank += (kj < my_key || (kj == my_key && j < tid)) ? 1 : 0;
+      // nearest slabs first: rank by (key, list position), kSortPer listed slabs per thread (one for
+      // lists up to the workgroup size, i.e. practically always: c3 28 slabs per tile on average,
+      // 116 at most; c5 58 / 235).  (One wave exchanging the keys by v_readlane instead of LDS, and
+      // skipping lists shorter than 8 or 16: all slower, 0.275-0.281 vs 0.270 ms on c3.)
+      constexpr int kSortPer = (kSortMax + kBlock - 1) / kBlock;
+      int my_slab[kSortPer], rank[kSortPer];
+#pragma unroll
+      for (int q = 0; q < kSortPer; ++q) {
+        const int e = tid + q * kBlock;
+        my_slab[q] = 0; rank[q] = 0;
+        if (e < scnt && (q == 0 || scnt > q * kBlock)) {
+          my_slab[q] = s_slab[e];
+          const float my_key = s_skey[e];
+          for (int j = 0; j < scnt; ++j) {
+            const float kj = s_skey[j];
+            rank[q] += (kj < my_key || (kj == my_key && j < e)) ? 1 : 0;
+          }
         }
       }
       __syncthreads();
-      if (tid < scnt) s_slab[rank] = my_slab;
+#pragma unroll
+      for (int q = 0; q < kSortPer; ++q)
+        if (tid + q * kBlock < scnt) s_slab[rank[q]] = my_slab[q];
       __syncthreads();
     }
 #if RTGS_STAMPS
     if (st[1] == 0) st[1] = __builtin_amdgcn_s_memtime();
+    c_slabs += scnt;
 #endif
 
     // ---- expand the listed slabs into the survivor list, then trace it; in ROUNDS only when the
@@ -1153,7 +1169,8 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
     unsigned hwid, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    sp[5] = (unsigned long long)c_iter | ((unsigned long long)c_hit << 16) | ((unsigned long long)c_ins << 32);
+    sp[5] = (unsigned long long)c_iter | ((unsigned long long)c_hit << 16) | ((unsigned long long)c_ins << 32) |
+            ((unsigned long long)min(c_slabs, 65535) << 48);
     sp[6] = t_front; sp[7] = t_ins; (void)hwid; (void)xcc;
   }
 #endif

@@ -30,6 +30,9 @@ for world in (1, 8):
           f"first start to last end {span_us:.1f} us")
     packed = raw[:, 5]
     cnts = np.stack([packed & 0xFFFF, (packed >> 16) & 0xFFFF, (packed >> 32) & 0xFFFF], axis=1).astype(np.float64)
+    slabs = ((packed >> 48) & 0xFFFF)[raw[:, 0] > 0]
+    print(f"   surviving slabs per tile: mean {slabs.mean():.0f}, p50 {np.median(slabs):.0f}, p95 {np.percentile(slabs, 95):.0f}, "
+          f"max {slabs.max()}; tiles above 256: {(slabs > 256).mean():.1%}")
     t_front, t_ins = raw[:, 6].astype(np.float64), raw[:, 7].astype(np.float64)
     live_ = raw[:, 0] > 0
     ni = np.maximum(cnts[:, 2], 1)
