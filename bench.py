@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="c3", help="c2 | c3 | c5 (SURVEY.md 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-scene-hit", action="store_true", help="skip the arbitrary-ray Scene.hit figure")
     ap.add_argument("--cpu-rays", type=int, default=256, help="rays of the NumPy baseline sample")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo "
                     "only for functional rehearsal of the N > 1 path)")
@@ -82,6 +83,31 @@ def cpu_baseline(cfg, arrays, cam, n_rays):
                                "sample": f"{n2} seeded random pixels, C fp64 one-pass, {dt2:.1f} s"}
     except Exception as exc:  # the optional line must never break the bench
         out["c_openmp"] = {"error": repr(exc)}
+    return out
+
+
+def closest_hit_rates(scene, cam):
+    """Secondary figure: arbitrary-ray Scene.hit throughput on the
+    960x540 generated camera rays of the same pose, through the slab-box structure and, once, by
+    brute force (same answers: tests/test_gpu_primitives.py)."""
+    import rtgs
+    w, h = 960, 540
+    camera = rtgs.Camera(cam["position"], cam["rotation"], (w, h), (float(h), float(h)))
+    camera.generate_ray_field(camera.position, camera.rotation)
+    rays = camera.cam_ray_field.data
+    scene.accel()
+    out = {}
+    for name, brute, reps in (("accel", False, 5), ("brute_force", True, 1)):
+        scene.hit_batch(rays, brute_force=brute)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            idx, _ = scene.hit_batch(rays, brute_force=brute)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        out[name] = {"rays_per_s": w * h / dt, "ms": dt * 1e3}
+    out["rays"] = w * h
+    out["hit_fraction"] = float((idx >= 0).float().mean())
     return out
 
 
@@ -257,6 +283,8 @@ def main():
         }
         line["secondary"] = {"closest_hit_queries_per_s": mrays * 1e6 * cfg.depth,
                              "frame_ms_median_hip_events": frame_ms_median}
+        if world == 1 and not args.no_scene_hit:
+            line["secondary"]["scene_hit_960x540"] = closest_hit_rates(scene, cam)
         if verified is not None:
             line["verified"] = verified
         if world == 1 and not args.no_cpu_baseline:

@@ -183,6 +183,21 @@ int rtgs_untile(const float* compact, int32_t world, int32_t tiles_per_rank, int
 int rtgs_closest_hit(const RtgsScene* scene, int32_t n_rays, const float* rays,
                      int32_t* hit_idx, float* hit_t, rtgs_stream_t stream);
 
+/* Acceleration structure for the two arbitrary-ray queries (what the reference's BVH is to its
+ * Scene.hit, scene.py:162-450): per-Gaussian fp64 inverse covariances, exact world-space boxes of
+ * every 64 consecutive Gaussians and of every 16 such slabs.  It helps when consecutive Gaussians
+ * are spatially close (rtgs.Scene stores them in Morton order); answers are identical to the
+ * brute-force calls for any order.  Build once per scene (caller-owned buffer of
+ * rtgs_accel_bytes(n) bytes, 16-B aligned), rebuild when the Gaussians change.
+ * accel == NULL in the *_accel calls means brute force. */
+size_t rtgs_accel_bytes(int32_t n);
+int rtgs_accel_build(const RtgsScene* scene, void* accel, size_t accel_bytes, rtgs_stream_t stream);
+int rtgs_closest_hit_accel(const RtgsScene* scene, const void* accel, size_t accel_bytes, int32_t n_rays,
+                           const float* rays, int32_t* hit_idx, float* hit_t, rtgs_stream_t stream);
+int rtgs_sample_step_rays_accel(const RtgsScene* scene, const void* accel, size_t accel_bytes,
+                                int32_t n_rays, float* rays, float* sample_buf, float* attenuation_buf,
+                                rtgs_stream_t stream);
+
 /* RayTracer.sample_step (ray_tracer.py:79-104) for an ARBITRARY ray field, literally: Scene.hit by
  * brute force, Gaussian.eval at the chord midpoint (t1+t2)/2 along ray.direction, sample +=
  * attenuation * alpha * rgb, attenuation *= 1 - alpha, ray.start = t1 + 1e-8 (+inf on a miss).

@@ -140,10 +140,143 @@ __device__ __forceinline__ Closest closest_hit_block(int32_t n, const float* __r
   return c;
 }
 
+// ---- acceleration structure for arbitrary-ray queries -------------------------------------
+// The reference answers Scene.hit through a binned-SAH BVH over loose per-Gaussian boxes
+// (scene.py:162-450, gaussian.py:104-138).  Here: the scene is stored in Morton order, so 64
+// consecutive Gaussians (a slab) are spatially compact; the structure is, per Gaussian, the fp64
+// inverse covariance (built ONCE per scene instead of once per workgroup per query), per slab the
+// exact world-space box of its members' ellipsoids {d^T Sigma^-1 d <= 3} (half-extent sqrt(3 Sigma_ii)),
+// and per 16 slabs the union of those.  A wave walks groups -> slabs -> Gaussians in index
+// order; a box is skipped when no lane's ray can have a hit in it inside (start, min(end, best t1)).
+// Same candidates' arithmetic as the brute-force kernel, same lowest-index tie rule: same answers.
+constexpr int kAccGroup = 16;   // slabs per group box
+constexpr int kBoxFloats = 8;   // lo xyz, hi xyz, 2 pad: one 32-B scalar load
+
+struct AccelView {
+  const double* minv;      // [nn][6]
+  const float* slab_box;   // [nslabs][8]
+  const float* group_box;  // [ngroups][8]
+  int32_t nslabs, ngroups;
+};
+
+__host__ __device__ inline size_t accel_nn(int32_t n) { return ((size_t)n + 63) & ~(size_t)63; }
+
+__global__ __launch_bounds__(256) void k_accel_build(int32_t n, const float* __restrict__ pos,
+                                                      const float* __restrict__ rot,
+                                                      const float* __restrict__ scale,
+                                                      double* __restrict__ minv, float* __restrict__ slab_box) {
+  const int g0 = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = g0 < n;
+  const int g = live ? g0 : n - 1;
+  double m6[6];
+  cov_inverse6(rot + 4 * (size_t)g, scale + 3 * (size_t)g, m6);
+  float lo[3] = {kInf, kInf, kInf}, hi[3] = {-kInf, -kInf, -kInf};
+  if (live) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) minv[6 * (size_t)g + k] = m6[k];
+    // Sigma_ii = sum_k R_ik^2 s_k^2 with the reference's R = |q|^2 x rotation (gaussian.py:100-101)
+    const double q[4] = {rot[4 * g], rot[4 * g + 1], rot[4 * g + 2], rot[4 * g + 3]};
+    double R[9];
+    quat_to_mat3(q, R);
+    const double s2[3] = {(double)scale[3 * g] * scale[3 * g], (double)scale[3 * g + 1] * scale[3 * g + 1],
+                          (double)scale[3 * g + 2] * scale[3 * g + 2]};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const double sii = R[3 * i] * R[3 * i] * s2[0] + R[3 * i + 1] * R[3 * i + 1] * s2[1] + R[3 * i + 2] * R[3 * i + 2] * s2[2];
+      const double h = sqrt(3.0 * sii) * (1.0 + 1e-9);
+      lo[i] = __double2float_rd((double)pos[3 * g + i] - h);   // rounded outwards; NaN stays NaN: ignored below
+      hi[i] = __double2float_ru((double)pos[3 * g + i] + h);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      lo[i] = fminf(lo[i], __shfl_xor(lo[i], off));
+      hi[i] = fmaxf(hi[i], __shfl_xor(hi[i], off));
+    }
+  }
+  if ((threadIdx.x & (kWave - 1)) == 0 && live) {
+    float* b = slab_box + (size_t)(g0 / kWave) * kBoxFloats;
+    b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2]; b[3] = hi[0]; b[4] = hi[1]; b[5] = hi[2]; b[6] = 0.f; b[7] = 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_accel_groups(int32_t nslabs, const float* __restrict__ slab_box,
+                                                       float* __restrict__ group_box) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u * kAccGroup >= nslabs) return;
+  float lo[3] = {kInf, kInf, kInf}, hi[3] = {-kInf, -kInf, -kInf};
+  for (int k = 0; k < kAccGroup; ++k) {
+    const int sl = u * kAccGroup + k;
+    if (sl >= nslabs) break;
+    const float* b = slab_box + (size_t)sl * kBoxFloats;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { lo[i] = fminf(lo[i], b[i]); hi[i] = fmaxf(hi[i], b[3 + i]); }
+  }
+  float* o = group_box + (size_t)u * kBoxFloats;
+  o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2]; o[6] = 0.f; o[7] = 0.f;
+}
+
+// Can the ray (o + t d, fp32 as stored) have a point inside the box for some t in [t_lo, t_hi]?
+// Conservative: the slab distances are padded by 1e-6 relative.  A zero direction component
+// constrains nothing if the origin lies between the two planes, everything otherwise.
+__device__ __forceinline__ bool box_may_hit(const float* __restrict__ b, const float o[3], const float d[3],
+                                            const float inv[3], float t_lo, float t_hi) {
+  float tn = -kInf, tf = kInf;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float t0 = (b[i] - o[i]) * inv[i], t1 = (b[3 + i] - o[i]) * inv[i];
+    float a = fminf(t0, t1), c = fmaxf(t0, t1);
+    if (d[i] == 0.f) {
+      const bool in = o[i] >= b[i] && o[i] <= b[3 + i];
+      a = in ? -kInf : kInf;
+      c = in ? kInf : -kInf;
+    }
+    tn = fmaxf(tn, a);
+    tf = fminf(tf, c);
+  }
+  tn -= fabsf(tn) * 1e-6f;
+  tf += fabsf(tf) * 1e-6f;
+  return tn <= tf && tf >= t_lo && tn <= t_hi;
+}
+
+__device__ __forceinline__ Closest closest_hit_accel(const AccelView av, int32_t n, const float* __restrict__ pos,
+                                                     bool live, const double o[3], const double d[3],
+                                                     float start, float end) {
+  const double inf = __builtin_huge_val();
+  Closest c{-1, inf, inf};
+  const float fo[3] = {(float)o[0], (float)o[1], (float)o[2]};   // exact: rays are stored in fp32
+  const float fd[3] = {(float)d[0], (float)d[1], (float)d[2]};
+  const float inv[3] = {1.0f / fd[0], 1.0f / fd[1], 1.0f / fd[2]};
+  float t_hi = end;   // min(end, best t1 so far), rounded up
+  for (int u = 0; u < av.ngroups; ++u) {
+    const bool hu = live && box_may_hit(av.group_box + (size_t)u * kBoxFloats, fo, fd, inv, start, t_hi);
+    if (!__any(hu)) continue;
+    const int s_end = min(av.nslabs, (u + 1) * kAccGroup);
+    for (int sl = u * kAccGroup; sl < s_end; ++sl) {
+      const bool hs = hu && box_may_hit(av.slab_box + (size_t)sl * kBoxFloats, fo, fd, inv, start, t_hi);
+      if (!__any(hs)) continue;
+      const int g_end = min(n, (sl + 1) * kWave);
+      for (int g = sl * kWave; g < g_end; ++g) {
+        if (hs) {
+          const HitD h = hit_quadratic(o, d, pos + 3 * (size_t)g, av.minv + 6 * (size_t)g);
+          const float t1f = (float)h.t1;   // the window is tested in fp32: see closest_hit_block
+          if (t1f < end && t1f > start && h.t1 < c.t1) {
+            c.t1 = h.t1; c.t2 = h.t2; c.idx = g;
+            t_hi = fminf(t_hi, __double2float_ru(h.t1));
+          }
+        }
+      }
+    }
+  }
+  return c;
+}
+
 __global__ __launch_bounds__(kHitBlock) void k_closest_hit(int32_t n, const float* __restrict__ pos,
                                                             const float* __restrict__ rot,
                                                             const float* __restrict__ scale,
-                                                            int32_t n_rays,
+                                                            const AccelView av, int32_t n_rays,
                                                             const float* __restrict__ rays,
                                                             int32_t* __restrict__ hit_idx,
                                                             float* __restrict__ hit_t) {
@@ -159,7 +292,8 @@ __global__ __launch_bounds__(kHitBlock) void k_closest_hit(int32_t n, const floa
     d[0] = rp[3]; d[1] = rp[4]; d[2] = rp[5];
     start = rp[6]; end = rp[7];
   }
-  const Closest c = closest_hit_block(n, pos, rot, scale, live, o, d, start, end, s_mu, s_m);
+  const Closest c = av.minv ? closest_hit_accel(av, n, pos, live, o, d, start, end)
+                            : closest_hit_block(n, pos, rot, scale, live, o, d, start, end, s_mu, s_m);
   if (live) {
     hit_idx[r] = c.idx;
     hit_t[2 * r] = (float)c.t1;
@@ -180,6 +314,7 @@ __global__ __launch_bounds__(kHitBlock) void k_sample_step_rays(int32_t n, const
                                                                  const float* __restrict__ scale,
                                                                  const float* __restrict__ colop,
                                                                  const float* __restrict__ sh,
+                                                                 const AccelView av,
                                                                  int32_t n_rays, float* __restrict__ rays,
                                                                  float* __restrict__ sample,
                                                                  float* __restrict__ att) {
@@ -195,7 +330,8 @@ __global__ __launch_bounds__(kHitBlock) void k_sample_step_rays(int32_t n, const
     d[0] = rp[3]; d[1] = rp[4]; d[2] = rp[5];
     start = rp[6]; end = rp[7];
   }
-  const Closest c = closest_hit_block(n, pos, rot, scale, live, o, d, start, end, s_mu, s_m);
+  const Closest c = av.minv ? closest_hit_accel(av, n, pos, live, o, d, start, end)
+                            : closest_hit_block(n, pos, rot, scale, live, o, d, start, end, s_mu, s_m);
   if (!live) return;
   if (c.idx < 0) {
     rp[6] = kInf;   // ray_tracer.py:103-104
@@ -383,27 +519,73 @@ int rtgs_generate_rays(const RtgsCamera* cam, float* rays, rtgs_stream_t stream)
   return check_launch();
 }
 
-int rtgs_closest_hit(const RtgsScene* scene, int32_t n_rays, const float* rays, int32_t* hit_idx,
-                     float* hit_t, rtgs_stream_t stream) {
+size_t rtgs_accel_bytes(int32_t n) {
+  if (n <= 0) return 0;
+  const size_t nn = accel_nn(n), nslabs = nn / kWave, ngroups = (nslabs + kAccGroup - 1) / kAccGroup;
+  return nn * 6 * sizeof(double) + (nslabs + ngroups) * kBoxFloats * sizeof(float);
+}
+
+static int accel_view(const RtgsScene* scene, const void* accel, size_t accel_bytes, AccelView* av) {
+  *av = AccelView{nullptr, nullptr, nullptr, 0, 0};
+  if (!accel) return RTGS_OK;   // brute force
+  if (accel_bytes < rtgs_accel_bytes(scene->n)) return RTGS_EWORKSPACE;
+  if (reinterpret_cast<uintptr_t>(accel) & 15u) return RTGS_EINVAL;
+  const size_t nn = accel_nn(scene->n);
+  av->nslabs = (int32_t)(nn / kWave);
+  av->ngroups = (av->nslabs + kAccGroup - 1) / kAccGroup;
+  av->minv = static_cast<const double*>(accel);
+  av->slab_box = reinterpret_cast<const float*>(av->minv + nn * 6);
+  av->group_box = av->slab_box + (size_t)av->nslabs * kBoxFloats;
+  return RTGS_OK;
+}
+
+int rtgs_accel_build(const RtgsScene* scene, void* accel, size_t accel_bytes, rtgs_stream_t stream) {
+  if (!scene || scene->n <= 0 || !scene->position || !scene->rotation || !scene->scale || !accel) return RTGS_EINVAL;
+  AccelView av;
+  if (int rc = accel_view(scene, accel, accel_bytes, &av)) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(k_accel_build, grid_for(scene->n, 256), dim3(256), 0, s, scene->n, scene->position,
+                     scene->rotation, scene->scale, const_cast<double*>(av.minv), const_cast<float*>(av.slab_box));
+  hipLaunchKernelGGL(k_accel_groups, grid_for(av.ngroups, 256), dim3(256), 0, s, av.nslabs, av.slab_box,
+                     const_cast<float*>(av.group_box));
+  return check_launch();
+}
+
+int rtgs_closest_hit_accel(const RtgsScene* scene, const void* accel, size_t accel_bytes, int32_t n_rays,
+                           const float* rays, int32_t* hit_idx, float* hit_t, rtgs_stream_t stream) {
   if (!scene || scene->n <= 0 || !scene->position || !scene->rotation || !scene->scale) return RTGS_EINVAL;
   if (n_rays <= 0 || !rays || !hit_idx || !hit_t) return RTGS_EINVAL;
+  AccelView av;
+  if (int rc = accel_view(scene, accel, accel_bytes, &av)) return rc;
   hipLaunchKernelGGL(k_closest_hit, grid_for(n_rays, kHitBlock), dim3(kHitBlock), 0,
                      static_cast<hipStream_t>(stream), scene->n, scene->position, scene->rotation,
-                     scene->scale, n_rays, rays, hit_idx, hit_t);
+                     scene->scale, av, n_rays, rays, hit_idx, hit_t);
+  return check_launch();
+}
+
+int rtgs_closest_hit(const RtgsScene* scene, int32_t n_rays, const float* rays, int32_t* hit_idx,
+                     float* hit_t, rtgs_stream_t stream) {
+  return rtgs_closest_hit_accel(scene, nullptr, 0, n_rays, rays, hit_idx, hit_t, stream);
+}
+
+int rtgs_sample_step_rays_accel(const RtgsScene* scene, const void* accel, size_t accel_bytes, int32_t n_rays,
+                                float* rays, float* sample_buf, float* attenuation_buf, rtgs_stream_t stream) {
+  if (!scene || scene->n <= 0 || !scene->position || !scene->rotation || !scene->scale ||
+      !scene->color_opacity || n_rays < 0 || !rays || !sample_buf || !attenuation_buf)
+    return RTGS_EINVAL;
+  if (n_rays == 0) return RTGS_OK;
+  AccelView av;
+  if (int rc = accel_view(scene, accel, accel_bytes, &av)) return rc;
+  hipLaunchKernelGGL(k_sample_step_rays, grid_for(n_rays, kHitBlock), dim3(kHitBlock), 0,
+                     static_cast<hipStream_t>(stream), scene->n, scene->position, scene->rotation,
+                     scene->scale, scene->color_opacity, scene->sh, av, n_rays, rays, sample_buf,
+                     attenuation_buf);
   return check_launch();
 }
 
 int rtgs_sample_step_rays(const RtgsScene* scene, int32_t n_rays, float* rays, float* sample_buf,
                           float* attenuation_buf, rtgs_stream_t stream) {
-  if (!scene || scene->n <= 0 || !scene->position || !scene->rotation || !scene->scale ||
-      !scene->color_opacity || n_rays < 0 || !rays || !sample_buf || !attenuation_buf)
-    return RTGS_EINVAL;
-  if (n_rays == 0) return RTGS_OK;
-  hipLaunchKernelGGL(k_sample_step_rays, grid_for(n_rays, kHitBlock), dim3(kHitBlock), 0,
-                     static_cast<hipStream_t>(stream), scene->n, scene->position, scene->rotation,
-                     scene->scale, scene->color_opacity, scene->sh, n_rays, rays, sample_buf,
-                     attenuation_buf);
-  return check_launch();
+  return rtgs_sample_step_rays_accel(scene, nullptr, 0, n_rays, rays, sample_buf, attenuation_buf, stream);
 }
 
 int rtgs_gaussian_hit(int32_t n, const float* rays, const float* position, const float* rotation,

@@ -64,6 +64,12 @@ PROTOTYPES = {
     "rtgs_untile": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "rtgs_closest_hit": (c_int32, [POINTER(RtgsScene), c_int32, c_void_p, c_void_p, c_void_p,
                                    c_void_p]),
+    "rtgs_accel_bytes": (c_size_t, [c_int32]),
+    "rtgs_accel_build": (c_int32, [POINTER(RtgsScene), c_void_p, c_size_t, c_void_p]),
+    "rtgs_closest_hit_accel": (c_int32, [POINTER(RtgsScene), c_void_p, c_size_t, c_int32, c_void_p, c_void_p,
+                                         c_void_p, c_void_p]),
+    "rtgs_sample_step_rays_accel": (c_int32, [POINTER(RtgsScene), c_void_p, c_size_t, c_int32, c_void_p,
+                                              c_void_p, c_void_p, c_void_p]),
     "rtgs_precompute": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rtgs_render": (c_int32, [POINTER(RtgsScene), POINTER(RtgsCamera), c_int32, c_float, c_int32, c_int32,
                               c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

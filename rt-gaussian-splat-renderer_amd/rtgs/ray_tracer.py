@@ -94,14 +94,17 @@ class RayTracer:
         self.trace(1, flags=nat.TRACE_RESUME | nat.TRACE_ACCUMULATE,
                    position=self.camera.field_position, rotation=self.camera.field_rotation)
 
-    def sample_step_rays(self):
-        """The literal per-ray form of ``sample_step``: brute-force ``Scene.hit`` of every ray of
-        ``cam_ray_field`` exactly as stored (origin, direction, start, end)."""
+    def sample_step_rays(self, brute_force: bool = False):
+        """The literal per-ray form of ``sample_step``: ``Scene.hit`` of every ray of
+        ``cam_ray_field`` exactly as stored (origin, direction, start, end), through the scene's
+        slab-box structure (``Scene.accel``) or, ``brute_force=True``, against every Gaussian."""
         rays = self.camera.cam_ray_field.data
         n = self.buf_size.x * self.buf_size.y
-        nat.check(nat.lib().rtgs_sample_step_rays(self.scene.native(), n, nat.ptr(rays),
-                                                  nat.ptr(self.sample_buf), nat.ptr(self.attenuation_buf),
-                                                  nat.stream()), "rtgs_sample_step_rays")
+        acc = None if brute_force else self.scene.accel()
+        nat.check(nat.lib().rtgs_sample_step_rays_accel(self.scene.native(), nat.ptr(acc),
+                                                        0 if acc is None else acc.numel(), n, nat.ptr(rays),
+                                                        nat.ptr(self.sample_buf), nat.ptr(self.attenuation_buf),
+                                                        nat.stream()), "rtgs_sample_step_rays")
 
     def sample_all(self, depth: int, t_cutoff: float = 0.0):
         """Extension: one WHOLE sample (``depth`` peels) in a single launch -- the result of

@@ -128,6 +128,7 @@ class Scene:
         self.version = 0            # bumped by commit(): invalidates cached projections
         self.order = None           # stream slot -> index into gaussian_field
         self.sort_spatially = True  # Morton-order the streamed copies (see morton_order)
+        self._accel = None          # (scene version, device buffer) of the arbitrary-ray structure
 
     # ---- construction ------------------------------------------------------------------
     @classmethod
@@ -228,9 +229,22 @@ class Scene:
         s.sh = nat.ptr(self.sh)
         return s
 
-    def hit_batch(self, rays):
+    def accel(self) -> torch.Tensor:
+        """The structure that stands in for the reference's BVH on arbitrary-ray queries
+        (scene.py:162-404 builds it in ``load_file``; here it is built on first use and after every
+        ``commit()``): fp64 inverse covariances + world-space slab boxes, ``rtgs_accel_build``."""
+        if self._accel is None or self._accel[0] != self.version:
+            need = nat.lib().rtgs_accel_bytes(self.num_gaussians)
+            buf = torch.empty(need, dtype=torch.uint8, device=self.position.device)
+            nat.check(nat.lib().rtgs_accel_build(self.native(), nat.ptr(buf), buf.numel(), nat.stream()),
+                      "rtgs_accel_build")
+            self._accel = (self.version, buf)
+        return self._accel[1]
+
+    def hit_batch(self, rays, brute_force: bool = False):
         """Closest hit of every ray of a ``RayField`` / (..., 8) device tensor
-        (scene.py:406-450).  Returns (gaussian_idx int32 (...), intersections float32 (..., 2))."""
+        (scene.py:406-450).  Returns (gaussian_idx int32 (...), intersections float32 (..., 2)).
+        ``brute_force=True`` tests every Gaussian against every ray (same answers, no structure)."""
         data = rays.data if isinstance(rays, RayField) else rays
         data = nat.require_device(data, "rays")
         shape = data.shape[:-1]
@@ -239,8 +253,10 @@ class Scene:
         t = torch.empty(shape + (2,), dtype=torch.float32, device=data.device)
         if n:
             scene = self.native()
-            nat.check(nat.lib().rtgs_closest_hit(scene, n, nat.ptr(data), nat.ptr(idx), nat.ptr(t),
-                                                 nat.stream()), "rtgs_closest_hit")
+            acc = None if brute_force else self.accel()
+            nat.check(nat.lib().rtgs_closest_hit_accel(scene, nat.ptr(acc), 0 if acc is None else acc.numel(), n,
+                                                       nat.ptr(data), nat.ptr(idx), nat.ptr(t), nat.stream()),
+                      "rtgs_closest_hit")
             # stream slot -> gaussian_field index
             idx = torch.where(idx >= 0, self.order[idx.clamp_min(0).long()].to(torch.int32), idx)
         return idx, t

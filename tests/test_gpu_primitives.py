@@ -181,6 +181,45 @@ def test_scene_hit_matches_the_oracle():
     assert scene.hit(new_ray(vec3(50, 50, 50), vec3(0, 1, 0))).gaussian_idx == -1
 
 
+def test_accelerated_scene_hit_equals_brute_force_bit_for_bit():
+    # the slab-box structure (what the reference's BVH is to Scene.hit, scene.py:162-450) only culls
+    # Gaussians a ray cannot hit: indices AND distances must equal the brute-force kernel's exactly,
+    # for coherent camera rays and for hostile ones (axis-parallel and zero directions, origins on box
+    # planes, unnormalised directions, finite windows), in Morton order and in the caller's order
+    from rtgs import synthetic
+    arrays = synthetic.make_capture_scene(20_000, 1.5, 77)
+    cam = synthetic.bench_camera(96, 64)
+    rng = np.random.default_rng(3)
+    for spatial in (True, False):
+        scene = rtgs.Scene()
+        scene.sort_spatially = spatial
+        scene.set_arrays(**arrays)
+        camera = rtgs.Camera(cam["position"], cam["rotation"], (96, 64), (cam["fx"], cam["fy"]))
+        camera.generate_ray_field(camera.position, camera.rotation)
+        coherent = camera.cam_ray_field.data.reshape(-1, 8).clone()
+        n = 6000
+        o = rng.uniform(-1.6, 1.6, (n, 3)).astype(np.float32)
+        d = rng.normal(size=(n, 3)).astype(np.float32) * rng.uniform(0.2, 3.0, (n, 1)).astype(np.float32)
+        d[:300, 0] = 0.0; d[300:600, 1:] = 0.0; d[600:610] = 0.0
+        o[:300, 0] = arrays["position"][:300, 0]          # origins on planes through Gaussian centres
+        start = np.where(rng.random(n) < 0.5, 0.0, rng.uniform(-0.5, 1.0, n)).astype(np.float32)
+        end = np.where(rng.random(n) < 0.4, rng.uniform(0.3, 3.0, n), np.inf).astype(np.float32)
+        hostile = torch.from_numpy(np.concatenate([o, d, start[:, None], end[:, None]], axis=1)).cuda()
+        for rays in (coherent, hostile):
+            ia, ta = scene.hit_batch(rays)
+            ib, tb = scene.hit_batch(rays, brute_force=True)
+            torch.cuda.synchronize()
+            assert torch.equal(ia, ib) and torch.equal(ta, tb)
+            assert int((ia >= 0).sum()) > 500
+    assert scene._accel is not None and scene._accel[0] == scene.version
+    v = scene.version
+    scene.commit()                                         # a re-committed scene rebuilds its structure
+    scene.hit_batch(coherent)
+    assert scene._accel[0] == v + 1
+    assert nat.lib().rtgs_closest_hit_accel(scene.native(), nat.ptr(scene.accel()), 64, 10, nat.ptr(coherent),
+                                            nat.ptr(ia), nat.ptr(ta), nat.stream()) == -3
+
+
 def test_scene_load_file():
     # reference tests/test_scene.py:16-23: loading tests/data/test.ply must not raise
     path = os.path.join(U.GOLDEN, "test.ply")
