@@ -23,12 +23,12 @@ class Camera:
         self.focal_length = vec2(focal_length)
         if self.buf_size.x <= 0 or self.buf_size.y <= 0:
             raise ValueError("buf_size must be positive")
+        # zero-initialised like the reference's field (camera.py:29): NOT camera rays until
+        # generate_ray_field fills it, so a sample_step before that traces the stored (null) rays
         self.cam_ray_field = Ray.field(shape=(self.buf_size.x, self.buf_size.y))
-        self.cam_ray_field.mark_edited(False)   # stands for this camera's rays until someone edits it
         # pose the ray field was last generated for: what sample_step traces
         self.field_position = vec3(position)
         self.field_rotation = vec4(rotation)
-        self.cam_ray_field.mark_edited(False)
 
     def native(self, position=None, rotation=None, device_pose=None) -> nat.RtgsCamera:
         return nat.make_camera(self.position if position is None else position,

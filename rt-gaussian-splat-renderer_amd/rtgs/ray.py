@@ -65,10 +65,12 @@ class Ray:
 class RayField:
     """A (shape..., 8) float32 device tensor of rays; element [I] is a ``Ray``.
 
-    ``edited`` records whether the field may differ from what ``Camera.generate_ray_field`` last
-    wrote (element assignment and ``init`` set it; writes through ``.data`` or the component
-    views cannot be seen -- call ``mark_edited()`` after those).  ``RayTracer.sample_step`` picks
-    its kernel by it."""
+    ``edited`` tells whether the field may differ from what ``Camera.generate_ray_field`` last
+    wrote: element assignment, ``init`` and ``mark_edited()`` set it, and so does any in-place
+    torch write through ``.data`` or the component views (``field.start[...] = x``), which bumps
+    the tensor's version counter.  A new field is edited: zeros are not camera rays.  The HIP
+    kernels write through raw pointers and do not count.  ``RayTracer.sample_step`` picks its
+    kernel by it."""
 
     def __init__(self, shape, data: torch.Tensor | None = None):
         self.shape = (shape,) if isinstance(shape, int) else tuple(int(s) for s in shape)
@@ -76,10 +78,20 @@ class RayField:
             data = torch.zeros(self.shape + (nat.RAY_FLOATS,), dtype=torch.float32,
                                device=nat.device())
         self.data = nat.require_device(data, "ray field")
-        self.edited = True      # not (yet) a generated camera ray field
+        self._edited = True     # not (yet) a generated camera ray field
+        self._clean_version = self.data._version
+
+    @property
+    def edited(self) -> bool:
+        return self._edited or self.data._version != self._clean_version
+
+    @edited.setter
+    def edited(self, value: bool) -> None:
+        self.mark_edited(value)
 
     def mark_edited(self, edited: bool = True) -> None:
-        self.edited = bool(edited)
+        self._edited = bool(edited)
+        self._clean_version = self.data._version
 
     def init(self, origin=(0, 0, 0), direction=(0, 1, 0), start=0, end=math.inf):
         """Run ``Ray.init`` (ray.py:20-41) on every element."""

@@ -54,7 +54,8 @@ class RayTracer:
         # one progressive sample share it
         pos = self.camera.position if position is None else position
         rot = self.camera.rotation if rotation is None else rotation
-        state = (id(self.scene), self.scene.version, ws.data_ptr(),
+        sc = self.scene
+        state = (id(sc), sc.version, sc.position._version, sc.rotation._version, sc.scale._version, ws.data_ptr(),
                  tuple(float(v) for v in pos), tuple(float(v) for v in rot),
                  tuple(float(v) for v in self.camera.focal_length))
         if not projected and state == self._projected_for:

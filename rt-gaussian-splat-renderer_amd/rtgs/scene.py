@@ -50,8 +50,11 @@ class SceneHit:
 def read_ply(path) -> dict:
     """Vertex element of an ASCII/binary-little-endian PLY as {property: ndarray}."""
     data = pathlib.Path(path).read_bytes()
-    marker = b"end_header\n"
-    end = data.find(marker)
+    end, marker = -1, b""
+    for marker in (b"end_header\n", b"end_header\r\n"):
+        end = data.find(marker)
+        if end >= 0:
+            break
     if not data.startswith(b"ply") or end < 0:
         raise ValueError(f"{path}: not a PLY file")
     lines = data[:end].decode("ascii").splitlines()
@@ -188,14 +191,21 @@ class Scene:
             has_sh = bool(torch.any(f.sh != 0).item())
         self.sh = f.sh.reshape(n, 45)[o].contiguous() if has_sh else None
 
-    def load_file(self, path: pathlib.Path, scale: float = 1):
+    def load_file(self, path: pathlib.Path, scale: float = 1, sh_layout: str = "inria"):
         """Load an INRIA-3DGS PLY (scene.py:89-131): wxyz -> xyzw (:103), normalised
         quaternions (:110-111), exp(scale) * scale (:112), sigmoid colour and opacity
         (:113-114), f_rest reshaped (-1, 3, 15) (:106-107).
 
         The kernel-side contract of the reference (scene.py:143-157) is that coefficient k of
-        Gaussian i is an RGB triple; the channel-major (3, 15) block is therefore transposed to
-        (15, 3) here (SURVEY.md 8c-i records that Taichi's own ingest cannot be checked)."""
+        Gaussian i is an RGB triple.  INRIA 3DGS files store f_rest channel-major (15 red, 15 green,
+        15 blue), which the reference reshapes to (-1, 3, 15) and hands to a (N, 15) vec3 field
+        without a transpose (scene.py:106-107, 122, 127); what Taichi makes of that shape cannot be
+        checked here.  ``sh_layout="inria"`` (default) transposes to (15, 3), the
+        reading under which the colours are the ones the file's author trained;
+        ``sh_layout="reference_raw"`` reinterprets the 45 values in memory order as (15, 3), what a
+        flat copy into the reference's field would give."""
+        if sh_layout not in ("inria", "reference_raw"):
+            raise ValueError("sh_layout must be 'inria' or 'reference_raw'")
         p = read_ply(pathlib.Path(path))
         num_points = len(p["x"])
         logger.info(f"Point cloud loaded from {path} with {num_points} points.")
@@ -207,7 +217,10 @@ class Scene:
         sh = None
         if all(f"f_rest_{i}" in p for i in range(45)):
             sh = np.stack([p[f"f_rest_{i}"] for i in range(45)], axis=-1).astype(f32)
-            sh = np.ascontiguousarray(sh.reshape(-1, 3, 15).transpose(0, 2, 1))
+            if sh_layout == "inria":
+                sh = np.ascontiguousarray(sh.reshape(-1, 3, 15).transpose(0, 2, 1))
+            else:
+                sh = np.ascontiguousarray(sh.reshape(-1, 15, 3))
         opacities = p["opacity"].astype(f32)
         rotations = rotations / np.linalg.norm(rotations, axis=-1)[:, np.newaxis]
         scales = (np.exp(scales) * f32(scale)).astype(f32)

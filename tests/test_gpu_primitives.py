@@ -181,6 +181,38 @@ def test_scene_hit_matches_the_oracle():
     assert scene.hit(new_ray(vec3(50, 50, 50), vec3(0, 1, 0))).gaussian_idx == -1
 
 
+def test_ply_sh_layouts_and_crlf_header(tmp_path):
+    # f_rest of an INRIA file is channel-major (15 R, 15 G, 15 B); the reference reshapes it
+    # (-1, 3, 15) for a (N, 15) vec3 field (scene.py:106-107, 122, 127).  Both readings are offered
+    # and each is pinned by a hand-computed pixel: one Gaussian on the optical axis, viewed along
+    # d = (0, 0, -1), where only Y_11, Y_22 and Y_33 are non-zero (gaussian.py:149-163).
+    import math
+    names = ["x", "y", "z", "nx", "ny", "nz", "f_dc_0", "f_dc_1", "f_dc_2"] + [f"f_rest_{i}" for i in range(45)] + \
+            ["opacity", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2", "rot_3"]
+    f_rest = (np.arange(45, dtype=np.float32) - 22.0) * np.float32(0.004)
+    row = np.concatenate([[0, 0, -4, 0, 0, 0, 0.2, -0.1, 0.4], f_rest, [50.0, math.log(0.2)] * 1 + [math.log(0.2)] * 2,
+                          [1, 0, 0, 0]]).astype("<f4")
+    for eol in (b"\n", b"\r\n"):
+        header = eol.join([b"ply", b"format binary_little_endian 1.0", b"element vertex 1"] +
+                          [b"property float " + n.encode() for n in names] + [b"end_header"]) + eol
+        path = tmp_path / ("crlf.ply" if eol == b"\r\n" else "lf.ply")
+        path.write_bytes(header + row.tobytes())
+        c0, c2, c6 = math.sqrt(3 / math.pi), math.sqrt(5 / math.pi), math.sqrt(7 / math.pi)
+        Y = {1: 0.5 * c0 * -1.0, 5: 0.25 * c2 * 2.0, 11: 0.25 * c6 * (5.0 + 3.0)}     # y_33 as coded: 5 z^2 - 3 z
+        base = 1.0 / (1.0 + np.exp(-np.array([0.2, -0.1, 0.4])))
+        for layout, coef in (("inria", lambda k, c: f_rest[c * 15 + k]), ("reference_raw", lambda k, c: f_rest[3 * k + c])):
+            scene = rtgs.Scene()
+            scene.load_file(path, sh_layout=layout)
+            camera = rtgs.Camera((0, 0, 0), (0, 0, 0, 1), (5, 5), (5.0, 5.0))
+            tracer = rtgs.RayTracer((5, 5), scene, camera)
+            tracer.sample_all(16)
+            torch.cuda.synchronize()
+            want = [base[c] + sum(Y[k] * coef(k, c) for k in Y) for c in range(3)]    # opacity sigmoid(50) = 1
+            assert np_(tracer.sample_buf[2, 2]) == pytest.approx(want, abs=3e-6), (layout, eol)
+    with pytest.raises(ValueError):
+        rtgs.Scene().load_file(path, sh_layout="transposed")
+
+
 def test_accelerated_scene_hit_equals_brute_force_bit_for_bit():
     # the slab-box structure (what the reference's BVH is to Scene.hit, scene.py:162-450) only culls
     # Gaussians a ray cannot hit: indices AND distances must equal the brute-force kernel's exactly,
@@ -279,6 +311,34 @@ def test_cli_renders_headless(tmp_path):
     out2 = tmp_path / "syn.png"
     assert main(["--synthetic", "2000", "-r", "128,72", "--radius", "3", "--one-pass", "--out", str(out2)]) == 0
     assert out2.read_bytes().startswith(b"\x89PNG")
+
+
+def test_cli_image_matches_the_oracle_at_an_orbit_pose(tmp_path):
+    # the CLI's orbit pose (reference __main__.py:120-142) drives a real render whose
+    # 8-bit image is compared with the C oracle's for the same scene and pose, written through the
+    # image convention img[H-1-j, i] (camera.py:33-35)
+    from oracle import c_oracle
+    from rtgs import synthetic
+    from rtgs.__main__ import main, orbit_pose
+    import scenes
+    w, h, fov = 120, 80, 70.0
+    theta, phi, r = 0.6, 1.1, 3.2
+    out = str(tmp_path / "orbit.ppm")
+    assert main(["--synthetic", "3000", "-r", f"{w},{h}", "-f", str(fov), "-d", "16", "--theta", str(theta),
+                 "--phi", str(phi), "--radius", str(r), "--cursor", "0.1,-0.05,0.2", "--out", out]) == 0
+    data = open(out, "rb").read()
+    head = b"P6\n%d %d\n255\n" % (w, h)
+    got = np.frombuffer(data[len(head):], np.uint8).reshape(h, w, 3).astype(np.int32)
+    pos, quat = orbit_pose(theta, phi, r, (0.1, -0.05, 0.2))
+    focal = float(np.float32((h / 2) / np.tan(fov * np.pi / 360)))
+    cam = dict(position=scenes.f32_tuple(pos), rotation=scenes.f32_tuple(quat), width=w, height=h, fx=focal, fy=focal)
+    arrays = synthetic.make_scene(3000, w / h, 1)
+    want = c_oracle.render(arrays, cam, 16)
+    img = np.clip(want["sample"].reshape(w, h, 3), 0.0, 1.0)
+    want8 = (np.transpose(img, (1, 0, 2))[::-1] * 255.0 + 0.5).astype(np.int32)
+    solid = np.transpose((~want["fragile"]).reshape(w, h), (1, 0))[::-1]
+    assert np.abs(got - want8)[solid].max() <= 1            # one 8-bit step: rounding of values at x.5
+    assert (np.abs(got - want8)[solid] == 0).mean() > 0.99 and want8.max() > 100 and solid.mean() > 0.99
 
 
 def test_headless_cli_renders_a_ply_and_a_synthetic_scene(tmp_path, capsys):

@@ -239,9 +239,9 @@ def test_edited_ray_field_is_traced_ray_by_ray(sh):
     from oracle import rtgs_ref as ref
     arrays, camera, tracer, rays = _edited_field_case(sh)
     w, h = camera.buf_size.x, camera.buf_size.y
+    assert not camera.cam_ray_field.edited                 # freshly generated
     camera.cam_ray_field.data.copy_(torch.from_numpy(rays.reshape(w, h, 8)))
-    assert not camera.cam_ray_field.edited
-    camera.cam_ray_field.mark_edited()
+    assert camera.cam_ray_field.edited                     # an in-place torch write is seen by itself
     tracer.clear_sample(); tracer.clear_attenuation()
     osc = ref.OracleScene(**arrays)
     want = (rays.astype(np.float64), np.zeros((w * h, 3)), np.ones(w * h))
@@ -261,6 +261,38 @@ def test_edited_ray_field_is_traced_ray_by_ray(sh):
     assert not camera.cam_ray_field.edited
     camera.cam_ray_field[3, 4] = rtgs.new_ray((0, 0, 3), (0, 0, -1))
     assert camera.cam_ray_field.edited
+
+
+def test_ray_field_and_scene_edits_are_noticed():
+    # (a) a NEW camera's zero-initialised field is not camera rays: sample_step before
+    # generate_ray_field traces the stored null rays (direction 0, end 0: nothing is hit), as the
+    # reference would; (b) writes through the component views mark the field edited; (c) the
+    # projection cache of the single-peel calls sees in-place edits of the streamed scene tensors
+    arrays, cam, depth = U.case("c1")
+    scene, camera, tracer = U.build(arrays, cam)
+    assert camera.cam_ray_field.edited
+    tracer.clear_attenuation()
+    tracer.sample_step()
+    torch.cuda.synchronize()
+    assert float(tracer.sample_buf.abs().max()) == 0.0 and bool(torch.isinf(camera.cam_ray_field.start).all())
+    camera.generate_ray_field(camera.position, camera.rotation)
+    assert not camera.cam_ray_field.edited
+    tracer.sample_step()                                   # a HIP kernel writing .start is not an edit
+    assert not camera.cam_ray_field.edited and float(tracer.sample_buf.abs().max()) > 0.0
+    camera.cam_ray_field.start[3:5, 2] = 0.25
+    assert camera.cam_ray_field.edited
+    camera.generate_ray_field(camera.position, camera.rotation)
+    assert not camera.cam_ray_field.edited
+    # (c)
+    tracer.clear_sample(); tracer.clear_attenuation()
+    tracer.sample_step()
+    first = tracer.sample_buf.clone()
+    scene.position[:, 0] += 0.3                            # in place, no commit(): still re-projected
+    camera.generate_ray_field(camera.position, camera.rotation)
+    tracer.clear_sample(); tracer.clear_attenuation()
+    tracer.sample_step()
+    torch.cuda.synchronize()
+    assert float((tracer.sample_buf - first).abs().max()) > 1e-2
 
 
 def test_per_ray_and_screen_space_sample_steps_agree_on_camera_rays():
