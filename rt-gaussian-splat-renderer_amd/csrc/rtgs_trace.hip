@@ -622,9 +622,8 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   const float dcx = X * a.inv_fx, dcy = Y * a.inv_fy;
   const float dlen = sqrtf(dcx * dcx + dcy * dcy + 1.0f);
 
-  const size_t pix = (size_t)pi * a.height + pj;
   float start = 0.f;
-  if ((a.flags & RTGS_TRACE_RESUME) && in_img) start = a.start[pix * a.start_stride];
+  if ((a.flags & RTGS_TRACE_RESUME) && in_img) start = a.start[((size_t)pi * a.height + pj) * a.start_stride];
 
   unsigned key[kK], kidx[kK];
   constexpr unsigned kEmpty = 0x7F800000u;  // +inf
@@ -823,8 +822,8 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
       int more = 0, total = 0;
 #pragma unroll
       for (int r = 0; r < kRegions; ++r) {
-        rc[r] = s_rcnt[r];
-        more |= s_rmore[r];
+        rc[r] = __builtin_amdgcn_readfirstlane(s_rcnt[r]);   // wave-uniform: SGPRs
+        more |= __builtin_amdgcn_readfirstlane(s_rmore[r]);
         total += rc[r];
       }
 #if RTGS_STAMPS
@@ -1068,6 +1067,13 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   st[3] = __builtin_amdgcn_s_memtime();
 #endif
   // ---- front-to-back compositing of the sorted list (ray_tracer.py:88-104) ----
+  // The pixel's coordinates and linear index are formed again from the lane number (laundered, so
+  // that the compiler cannot keep the prologue's copies alive through the candidate loop: they
+  // were 5 of the 9 VGPRs it spilled to scratch, 49 MB of HBM writes per c3 frame).
+  int lane_e = lane;
+  asm volatile("" : "+v"(lane_e));
+  const int pi_e = wi0 + (lane_e >> 3), pj_e = wj0 + (lane_e & 7);
+  const size_t pix = (size_t)pi_e * a.height + pj_e;
   float T = 1.f;
 #if !RTGS_STAMPS
   if ((a.flags & RTGS_TRACE_RESUME) && in_img) T = a.att[pix];
@@ -1150,7 +1156,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   }
 
   if (a.flags & RTGS_TRACE_COMPACT) {
-    float* o = a.sample + ((size_t)ltile * kTile * kTile + (size_t)(pi - mi0) * kTile + (pj - mj0)) * 3;
+    float* o = a.sample + ((size_t)ltile * kTile * kTile + (size_t)(pi_e - mi0) * kTile + (pj_e - mj0)) * 3;
     *reinterpret_cast<Rgb*>(o) = Rgb{L0, L1, L2};   // one 12-B store per lane
   } else if (in_img) {
     float* o = a.sample + pix * 3;
