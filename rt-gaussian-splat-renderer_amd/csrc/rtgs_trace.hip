@@ -63,7 +63,7 @@ namespace {
 #define RTGS_WAVES_PER_SIMD_MAIN 7   // the whole-frame instantiation (no SH, <= 4096 slabs): 72 VGPRs
 #endif
 #ifndef RTGS_WAVES_PER_SIMD_SH
-#define RTGS_WAVES_PER_SIMD_SH 4   // the SH variant carries 15 basis values more per lane
+#define RTGS_WAVES_PER_SIMD_SH 5   // the SH variant carries 15 basis values more per lane (c5: 1.54 ms at 5 with 2 gathers in flight, 1.60 at 4 / 4)
 #endif
 #ifndef RTGS_LDS_W
 #define RTGS_LDS_W 1      // 1: list = (t1, index|slot) registers + exponent in LDS by slot (one-wave K = 16 form)
@@ -104,7 +104,7 @@ namespace {
 #define RTGS_EXPAND_BIG 4
 #endif
 #ifndef RTGS_GROUP_BIG
-#define RTGS_GROUP_BIG 4   // c5: 1.53 ms vs 1.67 with 8 (register pressure of the SH variant), 1.54 with 2
+#define RTGS_GROUP_BIG 2   // c5: register pressure of the SH variant decides (8: 1.67 ms, 4: 1.53-1.60, 2: 1.54)
 #endif
 #ifndef RTGS_SLAB_CAP
 #define RTGS_SLAB_CAP 768
@@ -1013,7 +1013,10 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
           tm = tmnext;
         }
       }
-      __syncthreads();  // everyone is done with the list before the next round (or the next scan) refills it
+      // everyone is done with the list before the next round, the next scan or (two-wave form) the
+      // list hand-over refills its LDS; after a tile's LAST round nothing does, and the waves go on
+      // to their compositing without waiting for the slowest of the four
+      if (kSplit == 2 || more || !last) __syncthreads();
       if (!more) break;
     }
     scnt = 0;
