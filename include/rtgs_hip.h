@@ -56,7 +56,7 @@ typedef void* rtgs_stream_t;
  * an inverse covariance ROUNDED to fp32 moves delta/(4A) by ~2e-4 for a 70:1 needle Gaussian,
  * enough to flip grazing hits against the fp64 oracle (found by tools/fuzz_gpu.py). */
 typedef struct RtgsScene {
-  int32_t n;
+  int32_t n;                  /* 1 .. 2^26 (67 M) for the render path: RTGS_EINVAL beyond */
   const float* position;      /* [n][3]  Gaussian.position                         */
   const float* rotation;      /* [n][4]  Gaussian.rotation, xyzw                   */
   const float* scale;         /* [n][3]  Gaussian.scale                            */

@@ -161,6 +161,8 @@ constexpr int kSuper = RTGS_SUPER;
 #define RTGS_SORT_MAX 4096   // capped by the LDS the depth keys can borrow: kListCap floats (512 / 1024)
 #endif
 
+constexpr int32_t kMaxGaussians = 1 << 26;   // 67 M: a record's byte offset (64 B each) fits 32 bits
+
 struct TraceArgs {
   int32_t n;
   int32_t width, height;
@@ -453,6 +455,8 @@ __global__ __launch_bounds__(256) void k_super_bbox(int32_t nslabs, const float4
 // ------------------------------------------------------------------------------------
 
 struct Rgb { float r, g, b; };
+// HIP's __any() goes through an int (v_cndmask 0/1 + v_cmp_ne): the ballot form is the compare itself
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 // Per-lane list of the RTGS_MAX_DEPTH smallest entry distances: three register arrays (t1 bits,
 // Gaussian index, exponent), sorted ascending, empty slots = +inf.  Keys are the t1 bits alone
 // (t1 > 0, so unsigned order == float order); exactly equal t1 (a few dozen pixels per frame)
@@ -857,7 +861,6 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
         float tm, tmnext = 0.f;
         fetch(0, g, wb, tm);
         for (int c = 0; c < total; c += kWave) {
-          if (c + kWave < total) fetch(c + kWave, gnext, wbnext, tmnext);
           const bool pass = wb.x <= wXhi && wb.z >= wXlo && wb.y <= wYhi && wb.w >= wYlo;
           unsigned long long m = __ballot(pass);
           [[maybe_unused]] const unsigned long long m_all = m;
@@ -885,16 +888,20 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
             h = max(h, (unsigned)__builtin_amdgcn_update_dpp(0, (int)h, 0x140, 0xF, 0xF, false));   // row_mirror
             const unsigned hz = max(max((unsigned)__builtin_amdgcn_readlane((int)h, 0), (unsigned)__builtin_amdgcn_readlane((int)h, 16)),
                                     max((unsigned)__builtin_amdgcn_readlane((int)h, 32), (unsigned)__builtin_amdgcn_readlane((int)h, 48)));
-            if (hz < kEmpty) m &= __ballot(tm < __uint_as_float(hz));
+            // (evaluated even while hz is still +inf: this chunk's loads are all consumed before
+            // the next chunk's are issued, so nothing inside the candidate loop waits for memory)
+            m &= __ballot(tm < __uint_as_float(min(hz, kEmpty)) || hz >= kEmpty);
           }
+          if (c + kWave < total) fetch(c + kWave, gnext, wbnext, tmnext);
 #if RTGS_ABLATE >= 3
           asm volatile("" ::"s"(m));
           m = 0;
 #endif
           [[maybe_unused]] float pf = 0.f;
+          const unsigned long long img_m = __builtin_amdgcn_ballot_w64(in_img);
           while (m) {
             const int b = __builtin_ctzll(m);
-            m &= m - 1;
+            asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(b));   // m &= m - 1 in one SALU
 #if RTGS_STAMPS
             ++c_iter;
             t_loop0 = __builtin_amdgcn_s_memtime();
@@ -904,7 +911,9 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
             // one 64-B line, ONE s_load_dwordx16 (loaded as a single vector so that the compiler
             // cannot sink part of it behind the first branch and wait twice)
             typedef float Rec16 __attribute__((ext_vector_type(16)));
-            const Rec16 rq = *reinterpret_cast<const Rec16*>(rec + (size_t)gi * (kRecFloats / 4));
+            // 32-bit byte offset (n < 2^26, checked on the host): base + soffset, one SALU instead of four
+            const Rec16 rq = *reinterpret_cast<const Rec16*>(reinterpret_cast<const char*>(rec) +
+                                                             ((unsigned)gi * (unsigned)(kRecFloats * sizeof(float))));
             const float4 q0 = make_float4(rq[0], rq[1], rq[2], rq[3]), q1 = make_float4(rq[4], rq[5], rq[6], rq[7]),
                          q2 = make_float4(rq[8], rq[9], rq[10], rq[11]), q3 = make_float4(rq[12], rq[13], rq[14], rq[15]);
             // delta/4 = e_c + g.(x',y') - d1 (x' + l y')^2 - d2 y'^2 [- cr x y] about the record's
@@ -926,7 +935,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
             }
             // class 1 (general conic, or the camera within ~3.3 sigma): cross term, (y, x) storage
             // and A's own polynomial come from the tail, behind a scalar branch
-            const bool gen = q3.y != 0.f;
+            const bool gen = __float_as_uint(q3.y) != 0u;   // scalar integer compare (the flag is 0.0f or 1.0f)
             float A_gen = 0.f;
             if (__builtin_expect(gen, 0)) {
               const float4* tp = tail + (size_t)gi * (kTailFloats / 4);
@@ -944,7 +953,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
             asm volatile("" ::"v"(e));
             continue;
 #endif
-            if (!__any(hit)) continue;
+            if ((__builtin_amdgcn_ballot_w64(e > 0.f) & img_m) == 0ull) continue;
 #if RTGS_STAMPS
             ++c_hit;
 #endif
@@ -964,7 +973,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
             const bool cand = hit && t1 > start && t1 < kInf;  // scene.py:433
             const unsigned kn = cand ? __float_as_uint(t1) : ~0u;
             const bool ins = kn < key[kK - 1];
-            if (__any(ins)) {
+            if (wave_any(ins)) {
 #if RTGS_STAMPS
               ++c_ins;
               const unsigned long long ti0 = __builtin_amdgcn_s_memtime();
@@ -997,7 +1006,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
                 }
                 list_insert2<0, kTier>(key, kidx, kn, pn);
                 if constexpr (kTier < kK) {
-                  if (tier_short) tier_short = !__any(key[kTier - 1] < kEmpty);
+                  if (tier_short) tier_short = !wave_any(key[kTier - 1] < kEmpty);
                 }
               } else {
                 list_insert_par(key, kidx, wexp, kn, entry, wn);
@@ -1106,7 +1115,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
     if (done) break;
     // slots beyond the first `depth` only matter to lanes that dropped an exact t1 tie on the way
     // (the reference's peel loop peels on until `depth` DISTINCT entry distances are composited)
-    if (k0 >= a.depth && !__any(nhit < a.depth && key[k0] < kEmpty)) break;
+    if (k0 >= a.depth && !wave_any(nhit < a.depth && key[k0] < kEmpty)) break;
     float4 cog[kGroup];
     [[maybe_unused]] float wl[kGroup];
 #pragma unroll
@@ -1130,7 +1139,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
         // transmittance cut-off (extension, off by default): a ray below it stops compositing
         // -- as if it had missed, ray.start = +inf -- and a wave ballot ends the loop
         const bool live = valid && !(a.t_cutoff > 0.f && T < a.t_cutoff);
-        if (a.t_cutoff > 0.f && !__any(live)) { done = true; continue; }
+        if (a.t_cutoff > 0.f && !wave_any(live)) { done = true; continue; }
         prev_tbits = tbits;
         float4 co = cog[j];
         if (kHasSh) {
@@ -1256,6 +1265,7 @@ static int validate(const RtgsScene* scene, const RtgsCamera* cam, void* ws, siz
   if (!scene || !cam || !ws) return RTGS_EINVAL;
   if (scene->n <= 0 || !scene->position || !scene->rotation || !scene->scale || !scene->color_opacity)
     return RTGS_EINVAL;
+  if (scene->n > kMaxGaussians) return RTGS_EINVAL;   // 32-bit record offsets, index << 4 | slot payloads
   if (cam->width <= 0 || cam->height <= 0 || !(cam->fx > 0.f) || !(cam->fy > 0.f)) return RTGS_EINVAL;
   if (ws_bytes < rtgs_workspace_bytes(scene->n)) return RTGS_EWORKSPACE;
   if (reinterpret_cast<uintptr_t>(ws) & 15u) return RTGS_EINVAL;
