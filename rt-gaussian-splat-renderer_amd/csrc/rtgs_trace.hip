@@ -65,9 +65,6 @@ namespace {
 #ifndef RTGS_WAVES_PER_SIMD_SH
 #define RTGS_WAVES_PER_SIMD_SH 5   // the SH variant carries 15 basis values more per lane (c5: 1.54 ms at 5 with 2 gathers in flight, 1.60 at 4 / 4)
 #endif
-#ifndef RTGS_LDS_W
-#define RTGS_LDS_W 1      // 1: list = (t1, index|slot) registers + exponent in LDS by slot (one-wave K = 16 form)
-#endif
 #ifndef RTGS_LOOKAHEAD
 #define RTGS_LOOKAHEAD 1  // big scenes: touch the next candidate's record line one iteration ahead (scalar-cache
 #endif                    // prefetch).  c5 (64 MB of records) 1.74 -> 1.58 ms; c3 (6.4 MB, L2-resident) 0.188 -> 0.192: off there
@@ -99,6 +96,9 @@ namespace {
 #endif
 #ifndef RTGS_EXPAND
 #define RTGS_EXPAND 1      // c3: 0.185 ms with 1, 0.189 with 2, 0.194 with 4 (registers); c5 does not care
+#endif
+#ifndef RTGS_EXPAND_SPLIT
+#define RTGS_EXPAND_SPLIT 2
 #endif
 #ifndef RTGS_EXPAND_BIG
 #define RTGS_EXPAND_BIG 4
@@ -136,7 +136,7 @@ struct Tune {
 #endif
 constexpr int kBigSceneSlabs = RTGS_BIG_SLABS;   // scenes with more slabs than this use Tune<true>
 #ifndef RTGS_SPLIT_MAX_TILES
-#define RTGS_SPLIT_MAX_TILES 832
+#define RTGS_SPLIT_MAX_TILES 700
 #endif
 constexpr int kSplitMaxTiles = RTGS_SPLIT_MAX_TILES;
 #ifndef RTGS_TWO_LEVEL
@@ -548,7 +548,7 @@ __device__ __forceinline__ void sh_basis(float x, float y, float z, float (&Y)[R
 // bit as kSplit = 1.
 template <bool kHasSh, bool kBig, int kK, int kSplit>
 __global__ __launch_bounds__(kTraceBlock * kSplit,
-                             kHasSh ? RTGS_WAVES_PER_SIMD_SH
+                             kHasSh ? (kBig && kSplit == 1 ? RTGS_WAVES_PER_SIMD_SH : RTGS_WAVES_PER_SIMD)
                                     : (!kBig && kSplit == 1 && kK == RTGS_MAX_DEPTH ? RTGS_WAVES_PER_SIMD_MAIN
                                                                                     : RTGS_WAVES_PER_SIMD)) void k_trace(const TraceArgs a,
                                                           const float4* __restrict__ bbox,
@@ -566,14 +566,20 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
                 kWaves = TN::kWaves, kBlock = TN::kBlock;
   // the survivor list and (kSplit == 2) the list hand-over share one LDS pool: the hand-over
   // happens after the last barrier of the candidate loop
-  constexpr int kMergeWords = kSplit == 2 ? kWavesPerTile * 3 * kK * kWave : 0;
+  // (hand-over in two halves of kK/2 entries x {t1, payload}: 16 KB instead of 32)
+  constexpr int kMergeWords = kSplit == 2 ? kWavesPerTile * 2 * (kK / 2) * kWave : 0;
   constexpr int kListF4 = kListCap / 4;          // int indices; the 16-B bounds are re-read (L1) by the wave test
   constexpr int kPoolF4 = kListF4 > kMergeWords / 4 ? kListF4 : kMergeWords / 4;
   __shared__ float4 s_pool[kPoolF4];
   int* const s_idx = reinterpret_cast<int*>(s_pool);
   // exponents of the list entries, [slot][thread]: conflict-free whatever slots the lanes use
-  constexpr bool kLdsW = RTGS_LDS_W != 0 && kSplit == 1 && kK == RTGS_MAX_DEPTH;
+  constexpr bool kLdsW = kK == RTGS_MAX_DEPTH;
   static_assert(!kLdsW || kK == 16, "the payload keeps the slot in 4 bits");
+  static_assert(kLdsW || kSplit == 1, "the two-wave form exists for the full list only");
+  // payload = entry << kSlotBits | slot field; two-wave form: one more bit says whose LDS column
+  // (this wave's or the helper's) the slot is in, and the entry carries the arrival rank on top
+  constexpr int kSlotBits = kSplit == 2 ? 5 : 4;
+  constexpr unsigned kSlotMask = (1u << kSlotBits) - 1u;
   __shared__ float s_w[kLdsW ? kK * kBlock : 1];
   __shared__ int s_slab[kSlabCap];
   // depth keys of the first kSortMax listed slabs: only alive between the scan and the sort, when
@@ -583,7 +589,8 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   __shared__ int s_wcnt[2][kWaves];
   constexpr int kRegions = kWavesPerTile;            // expander waves = regions of the survivor list
   constexpr int kRegionCap = kListCap / kRegions;
-  constexpr int kExpand = kBig ? RTGS_EXPAND_BIG : RTGS_EXPAND;   // slabs one wave has in flight
+  // slabs one wave has in flight: more only pay where latency counts (the two-wave form's small launches)
+  constexpr int kExpand = kBig ? RTGS_EXPAND_BIG : (kSplit == 2 ? RTGS_EXPAND_SPLIT : RTGS_EXPAND);
   static_assert(kRegionCap >= kSlab, "a region must hold one whole slab");
   __shared__ int s_rcnt[kRegions], s_rmore[kRegions];
   constexpr int kSuperStep = kSlabIters * kBlock;   // slab groups scanned per outer step
@@ -636,7 +643,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
 #pragma unroll
   for (int k = 0; k < kK; ++k) {
     key[k] = kEmpty;
-    kidx[k] = kLdsW ? (unsigned)k : 0u;   // kLdsW: payload = index << 4 | slot
+    kidx[k] = kLdsW ? (unsigned)k | ((unsigned)role << 4) : 0u;   // kLdsW: payload = entry << kSlotBits | slot
   }
 #pragma unroll
   for (int k = 0; k < kWn; ++k) wexp[k] = 0.f;
@@ -656,7 +663,8 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
 #if RTGS_STAMPS
   unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
   int c_iter = 0, c_hit = 0, c_ins = 0, c_slabs = 0;
-  unsigned long long t_ins = 0, t_loop0 = 0, t_front = 0;
+  unsigned long long t_ins = 0, t_loop0 = 0, t_front = 0, t_exp = 0, t_bar = 0, t_merge = 0, t_mark = 0;
+  int c_rounds = 0;
   const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz: calibrates the shader clock
   st[0] = __builtin_amdgcn_s_memtime();
 #endif
@@ -788,6 +796,10 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
     int pos = min(scnt, wave * share);
     const int pend = wave < kRegions ? min(scnt, (wave + 1) * share) : pos;
     for (;;) {
+#if RTGS_STAMPS
+      t_mark = __builtin_amdgcn_s_memtime();
+      ++c_rounds;
+#endif
       int rcnt = 0;   // survivors this wave has listed in its region this round (wave-uniform)
       while (pos < pend) {
         // kExpand slabs in flight: one lane per Gaussian, 16-B bounds, coalesced
@@ -832,6 +844,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
       }
 #if RTGS_STAMPS
       if (st[2] == 0) st[2] = __builtin_amdgcn_s_memtime();
+      t_exp += __builtin_amdgcn_s_memtime() - t_mark;
 #endif
 #if RTGS_ABLATE == 4
       total = 0;
@@ -998,9 +1011,9 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
               }
               if constexpr (kLdsW) {
                 // the new entry takes the exponent slot of the entry that falls off the end
-                const unsigned slot = (tier_short ? kidx[kTier - 1] : kidx[kK - 1]) & 15u;
-                const unsigned pn = (entry << 4) | slot;
-                if (ins) s_wl[slot * kBlock] = wn;
+                const unsigned slot = (tier_short ? kidx[kTier - 1] : kidx[kK - 1]) & kSlotMask;
+                const unsigned pn = (entry << kSlotBits) | slot;
+                if (ins) s_wl[(slot & 15u) * kBlock] = wn;
                 if constexpr (kTier < kK) {
                   if (!tier_short) list_insert2<kTier, kK>(key, kidx, kn, pn);
                 }
@@ -1025,39 +1038,57 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
       // everyone is done with the list before the next round, the next scan or (two-wave form) the
       // list hand-over refills its LDS; after a tile's LAST round nothing does, and the waves go on
       // to their compositing without waiting for the slowest of the four
+#if RTGS_STAMPS
+      t_mark = __builtin_amdgcn_s_memtime();
+#endif
       if (kSplit == 2 || more || !last) __syncthreads();
+#if RTGS_STAMPS
+      t_bar += __builtin_amdgcn_s_memtime() - t_mark;
+#endif
       if (!more) break;
     }
     scnt = 0;
   }
   }
 
+#if RTGS_STAMPS
+  t_mark = __builtin_amdgcn_s_memtime();
+#endif
   if constexpr (kSplit == 2) {
     // ---- hand the helper wave's list over and merge: min(A[i], B[K-1-i]) is the bitonic
     // sequence of the K smallest of both; log2(K) half-cleaners sort it.  Order = (t1, arrival
-    // rank), the rank riding above the index bits of the entries (exact while a tile's stream has
-    // fewer than 2^(32 - idx_bits) candidates; beyond that only the order of exact ties is lost).
-    unsigned* const mp = reinterpret_cast<unsigned*>(s_pool) + sub * (3 * kK * kWave) + lane;
-    if (role == 1) {
+    // rank), the rank riding above the index bits of the entries (at least 10 bits: the host only
+    // picks this form for n <= 131072; exact while a tile's stream has fewer than 1024 candidates,
+    // beyond that only the order of exact ties is lost).
+    constexpr int kH = kK / 2;
+    unsigned* const mp = reinterpret_cast<unsigned*>(s_pool) + sub * (2 * kH * kWave) + lane;
+    // min(A[i], B[K-1-i]) for i < K/2 needs the helper's upper half, for i >= K/2 its lower half
 #pragma unroll
-      for (int k = 0; k < kK; ++k) {
-        mp[(0 * kK + k) * kWave] = key[k];
-        mp[(1 * kK + k) * kWave] = kidx[k];
-        mp[(2 * kK + k) * kWave] = __float_as_uint(wexp[k]);
+    for (int half = 0; half < 2; ++half) {
+      if (half == 1) __syncthreads();     // the first half has been read
+      if (role == 1) {
+#pragma unroll
+        for (int k = 0; k < kH; ++k) {
+          const int src = half == 0 ? kH + k : k;
+          mp[(0 * kH + k) * kWave] = key[src];
+          mp[(1 * kH + k) * kWave] = kidx[src];
+        }
+      }
+      __syncthreads();
+      if (role == 0) {
+#pragma unroll
+        for (int ii = 0; ii < kH; ++ii) {
+          const int i = half * kH + ii;          // this wave's slot
+          const int j = kK - 1 - i;              // the helper's slot it meets
+          const int k = half == 0 ? j - kH : j;  // where that slot sits in the hand-over block
+          const unsigned tb = mp[(0 * kH + k) * kWave], ib = mp[(1 * kH + k) * kWave];
+          const bool lt = tb < key[i] || (tb == key[i] && ib < kidx[i]);
+          key[i] = lt ? tb : key[i];
+          kidx[i] = lt ? ib : kidx[i];
+        }
       }
     }
-    __syncthreads();
     if (role == 1) return;
-#pragma unroll
-    for (int i = 0; i < kK; ++i) {
-      const int j = kK - 1 - i;
-      const unsigned tb = mp[(0 * kK + j) * kWave], ib = mp[(1 * kK + j) * kWave];
-      const float wb2 = __uint_as_float(mp[(2 * kK + j) * kWave]);
-      const bool lt = tb < key[i] || (tb == key[i] && ib < kidx[i]);
-      key[i] = lt ? tb : key[i];
-      kidx[i] = lt ? ib : kidx[i];
-      wexp[i] = lt ? wb2 : wexp[i];
-    }
 #pragma unroll
     for (int d = kK / 2; d > 0; d >>= 1) {
 #pragma unroll
@@ -1066,10 +1097,8 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
           const int j = i + d;
           const bool sw = key[j] < key[i] || (key[j] == key[i] && kidx[j] < kidx[i]);
           const unsigned t0 = key[i], i0 = kidx[i];
-          const float w0 = wexp[i];
           key[i] = sw ? key[j] : t0;   key[j] = sw ? t0 : key[j];
           kidx[i] = sw ? kidx[j] : i0; kidx[j] = sw ? i0 : kidx[j];
-          wexp[i] = sw ? wexp[j] : w0; wexp[j] = sw ? w0 : wexp[j];
         }
       }
     }
@@ -1077,6 +1106,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
 
 #if RTGS_STAMPS
   st[3] = __builtin_amdgcn_s_memtime();
+  t_merge = st[3] - t_mark;
 #endif
   // ---- front-to-back compositing of the sorted list (ray_tracer.py:88-104) ----
   // The pixel's coordinates and linear index are formed again from the lane number (laundered, so
@@ -1104,7 +1134,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
     const float in = 1.0f / sqrtf(wx * wx + wy * wy + wz * wz);  // gaussian.py:200
     sh_basis(wx * in, wy * in, wz * in, Ysh);
   }
-  [[maybe_unused]] const unsigned idx_mask = (1u << a.idx_bits) - 1u;
+  [[maybe_unused]] const unsigned idx_mask = kSplit == 2 ? (1u << a.idx_bits) - 1u : ~0u;
   int nhit = 0;
   float last_t = 0.f;
   unsigned prev_tbits = 0u;
@@ -1122,17 +1152,18 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
     for (int j = 0; j < kGroup; ++j) {
       const int k = k0 + j;
       const unsigned tb = key[k];
-      const unsigned gi = kSplit == 2 ? (kidx[k] & idx_mask) : (kLdsW ? kidx[k] >> 4 : kidx[k]);
+      const unsigned gi = kLdsW ? (kidx[k] >> kSlotBits) & idx_mask : kidx[k];
       cog[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (tb < kEmpty) cog[j] = colop[gi];
-      if constexpr (kLdsW) wl[j] = s_wl[(kidx[k] & 15u) * kBlock];
+      // the exponent: slot (kidx & 15) of this lane's column, or of the helper wave's (bit 4)
+      if constexpr (kLdsW) wl[j] = s_wl[(kidx[k] & 15u) * kBlock + (kSplit == 2 ? ((kidx[k] >> 4) & 1u) * kTraceBlock : 0u)];
     }
 #pragma unroll
     for (int j = 0; j < kGroup; ++j) {
       const int k = k0 + j;
       if (!done) {
         const unsigned tbits = key[k];
-        const unsigned gi = kSplit == 2 ? (kidx[k] & idx_mask) : (kLdsW ? kidx[k] >> 4 : kidx[k]);
+        const unsigned gi = kLdsW ? (kidx[k] >> kSlotBits) & idx_mask : kidx[k];
         // an exact repeat of the previous entry distance is what the reference's strict
         // `t1 > ray.start` drops (scene.py:433 after ray_tracer.py:101)
         const bool valid = tbits < kEmpty && tbits != prev_tbits && nhit < a.depth;
@@ -1181,7 +1212,8 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
 #if RTGS_STAMPS
   st[4] = __builtin_amdgcn_s_memtime();
   if (tid == 0 && a.att) {
-    unsigned long long* sp = reinterpret_cast<unsigned long long*>(a.att) + (size_t)blockIdx.x * 10;
+    unsigned long long* sp = reinterpret_cast<unsigned long long*>(a.att) + (size_t)blockIdx.x * 14;
+    sp[10] = t_exp; sp[11] = t_bar; sp[12] = t_merge; sp[13] = (unsigned long long)c_rounds;
     for (int k = 0; k < 5; ++k) sp[k] = st[k];
     sp[8] = rt0; sp[9] = __builtin_amdgcn_s_memrealtime();
     unsigned hwid, xcc;
@@ -1356,6 +1388,7 @@ static int trace_impl(const RtgsScene* scene, const RtgsCamera* cam, const RtgsT
   if (params->flags & RTGS_TRACE_SPLIT_ON) split = true;
   if (params->flags & RTGS_TRACE_SPLIT_OFF) split = false;
   if (params->depth == 1) split = false;
+  if (a.idx_bits > 17) split = false;   // two-wave entries: rank | index | 5 slot bits in 32; 10 rank bits need n <= 131072
 #define RTGS_LAUNCH(HAS_SH, BIG, K, SPLIT)                                                         \
   hipLaunchKernelGGL((k_trace<HAS_SH, BIG, K, SPLIT>), dim3(local), dim3(kTraceBlock * SPLIT), 0, s, a, \
                      bbox, slab_bbox, super_bbox, rec, tail, tmin, colop, sh)

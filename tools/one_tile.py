@@ -19,7 +19,7 @@ for (ti, tj) in [(60, 33), (46, 44), (10, 5), (60, 60)]:
     tile = tj * tx + ti
     for split in (0, 1):
         compact = b.alloc(1, T, T, 3)
-        stamps = torch.zeros((1, 10), dtype=torch.int64, device="cuda")
+        stamps = torch.zeros((1, 14), dtype=torch.int64, device="cuda")
         params = nat.RtgsTraceParams(cfg.depth, 0.0, tile, total, nat.TRACE_COMPACT | (nat.TRACE_SPLIT_ON if split else nat.TRACE_SPLIT_OFF))
         for _ in range(3):
             nat.check(nat.lib().rtgs_trace(scene.native(), camera.native(), params, nat.ptr(compact), stamps.data_ptr(),
@@ -31,4 +31,5 @@ for (ti, tj) in [(60, 33), (46, 44), (10, 5), (60, 60)]:
         clk = (raw[4] - raw[0]) / max(raw[9] - raw[8], 1) * 100
         print(f"tile ({ti},{tj}) split={split}: scan {d[0]} expand {d[1]} process {d[2]} composite {d[3]} cycles (total {raw[4]-raw[0]}, "
               f"{(raw[4]-raw[0])/clk:.1f} us at {clk:.0f} MHz); wave 0: iterations {it}, hits {hit}, insertions {ins}; "
-              f"front {raw[6]/max(ins,1):.0f} + network {raw[7]/max(ins,1):.0f} cycles per insertion")
+              f"front {raw[6]/max(ins,1):.0f} + network {raw[7]/max(ins,1):.0f} cycles per insertion; "
+              f"rounds {raw[13]}: expansion {raw[10]}, end-of-round barrier waits {raw[11]}, merge {raw[12]} cycles")

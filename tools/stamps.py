@@ -16,7 +16,7 @@ b.project()
 for world in (1, 8):
     per = (total + world - 1) // world
     compact = b.alloc(per, T, T, 3)
-    stamps = torch.zeros((per, 10), dtype=torch.int64, device="cuda")
+    stamps = torch.zeros((per, 14), dtype=torch.int64, device="cuda")
     params = nat.RtgsTraceParams(cfg.depth, 0.0, 0, world, nat.TRACE_COMPACT | (nat.TRACE_SPLIT_ON if os.environ.get('RTGS_SPLIT') == '1' else nat.TRACE_SPLIT_OFF))
     for _ in range(3):
         nat.check(nat.lib().rtgs_trace(scene.native(), camera.native(), params, nat.ptr(compact), stamps.data_ptr(),
