@@ -40,6 +40,8 @@
 
 #include <string.h>
 
+#include <type_traits>
+
 namespace rtgs {
 namespace {
 
@@ -581,7 +583,10 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   constexpr int kSlotBits = kSplit == 2 ? 5 : 4;
   constexpr unsigned kSlotMask = (1u << kSlotBits) - 1u;
   __shared__ float s_w[kLdsW ? kK * kBlock : 1];
-  __shared__ int s_slab[kSlabCap];
+  // surviving slab ids: 16 bits are enough below kBigSceneSlabs (4 096) slabs
+  using SlabId = typename std::conditional<kBig, int, unsigned short>::type;
+  static_assert(kBig || kBigSceneSlabs <= 65536, "slab ids of small scenes are stored in 16 bits");
+  __shared__ SlabId s_slab[kSlabCap];
   // depth keys of the first kSortMax listed slabs: only alive between the scan and the sort, when
   // the survivor pool is idle (every batch ends with a barrier) -- they share its LDS
   constexpr int kSortMax = RTGS_SORT_MAX < kListCap ? RTGS_SORT_MAX : kListCap;   // kListCap floats fit the pool
@@ -747,7 +752,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
     for (int it = 0; it < kSlabIters; ++it) {
       if ((keep_m[it] >> lane) & 1ull) {
         const int at = off + below(keep_m[it]);
-        s_slab[at] = slid[it];
+        s_slab[at] = (SlabId)slid[it];
         if (at < kSortMax) s_skey[at] = sk[it];
       }
       off += __popcll(keep_m[it]);
@@ -778,7 +783,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
       __syncthreads();
 #pragma unroll
       for (int q = 0; q < kSortPer; ++q)
-        if (tid + q * kBlock < scnt) s_slab[rank[q]] = my_slab[q];
+        if (tid + q * kBlock < scnt) s_slab[rank[q]] = (SlabId)my_slab[q];
       __syncthreads();
     }
 #if RTGS_STAMPS
@@ -810,7 +815,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
           gb[q] = make_float4(kInf, kInf, -kInf, -kInf);
           gbase[q] = 0;
           if (pos + q < pend) {
-            gbase[q] = __builtin_amdgcn_readfirstlane(s_slab[pos + q]) * kSlab;
+            gbase[q] = __builtin_amdgcn_readfirstlane((int)s_slab[pos + q]) * kSlab;
             if (gbase[q] + lane < a.n) gb[q] = bbox[gbase[q] + lane];
           }
         }
