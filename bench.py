@@ -283,6 +283,17 @@ def main():
         }
         line["secondary"] = {"closest_hit_queries_per_s": mrays * 1e6 * cfg.depth,
                              "frame_ms_median_hip_events": frame_ms_median}
+        if world == 1:
+            # the transmittance cut-off (extension, off in the headline: the reference has none)
+            cut = TileParallelRenderer(scene, camera, depth=cfg.depth, rank=0, world=1, t_cutoff=5e-5)
+            for _ in range(3):
+                cut.render_frame()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                cut.render_frame()
+            torch.cuda.synchronize()
+            line["secondary"]["frame_ms_with_t_cutoff_5e-5"] = (time.perf_counter() - t0) / 20 * 1e3
         if world == 1 and not args.no_scene_hit:
             line["secondary"]["scene_hit_960x540"] = closest_hit_rates(scene, cam)
         if verified is not None:

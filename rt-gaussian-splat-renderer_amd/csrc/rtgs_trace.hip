@@ -71,6 +71,9 @@ namespace {
 #define RTGS_LOOKAHEAD 1  // big scenes: touch the next candidate's record line one iteration ahead (scalar-cache
 #endif                    // prefetch).  c5 (64 MB of records) 1.74 -> 1.58 ms; c3 (6.4 MB, L2-resident) 0.188 -> 0.192: off there
 
+#ifndef RTGS_CUT_TRAVERSAL
+#define RTGS_CUT_TRAVERSAL 1   // t_cutoff > 0 also ends a tile's traversal (k_trace<..., kCut = true>)
+#endif
 #ifndef RTGS_HORIZON
 #define RTGS_HORIZON 1    // chunk-level horizon test against the per-Gaussian distance bound (see k_trace)
 #endif
@@ -457,6 +460,16 @@ __global__ __launch_bounds__(256) void k_super_bbox(int32_t nslabs, const float4
 // ------------------------------------------------------------------------------------
 
 struct Rgb { float r, g, b; };
+// wave-wide max / min of an unsigned value (DPP within rows of 16, then the four rows through SGPRs)
+__device__ __forceinline__ unsigned wave_umax(unsigned h) {
+  h = max(h, (unsigned)__builtin_amdgcn_update_dpp(0, (int)h, 0xB1, 0xF, 0xF, false));    // quad_perm 1,0,3,2
+  h = max(h, (unsigned)__builtin_amdgcn_update_dpp(0, (int)h, 0x4E, 0xF, 0xF, false));    // quad_perm 2,3,0,1
+  h = max(h, (unsigned)__builtin_amdgcn_update_dpp(0, (int)h, 0x141, 0xF, 0xF, false));   // row_half_mirror
+  h = max(h, (unsigned)__builtin_amdgcn_update_dpp(0, (int)h, 0x140, 0xF, 0xF, false));   // row_mirror
+  return max(max((unsigned)__builtin_amdgcn_readlane((int)h, 0), (unsigned)__builtin_amdgcn_readlane((int)h, 16)),
+             max((unsigned)__builtin_amdgcn_readlane((int)h, 32), (unsigned)__builtin_amdgcn_readlane((int)h, 48)));
+}
+__device__ __forceinline__ unsigned wave_umin(unsigned h) { return ~wave_umax(~h); }
 // HIP's __any() goes through an int (v_cndmask 0/1 + v_cmp_ne): the ballot form is the compare itself
 __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 // Per-lane list of the RTGS_MAX_DEPTH smallest entry distances: three register arrays (t1 bits,
@@ -548,7 +561,14 @@ __device__ __forceinline__ void sh_basis(float x, float y, float z, float (&Y)[R
 // heavy tile halves; at the end the second wave hands its list over through LDS and the first
 // merges (bitonic, ordered by (t1, index) = arrival order) and composites.  Same pixels bit for
 // bit as kSplit = 1.
-template <bool kHasSh, bool kBig, int kK, int kSplit>
+// kCut (t_cutoff > 0 only): the transmittance cut-off also ends a tile's TRAVERSAL.  Before each
+// chunk of 64 candidates the wave forms, per ray, the attenuation through the list entries nearer
+// than every candidate still to come in this round (suffix minimum of k_project's distance bounds
+// over the remaining chunks: those entries are final in value and position), exactly as the
+// compositing loop will; if every ray of the tile is below the cut-off there -- or already holds
+// `depth` final entries -- a wave ballot skips the rest of the round.  Exact: a terminated ray
+// composites nothing behind those entries, so the image equals the compositing-only cut-off's.
+template <bool kHasSh, bool kBig, int kK, int kSplit, bool kCut = false>
 __global__ __launch_bounds__(kTraceBlock * kSplit,
                              kHasSh ? (kBig && kSplit == 1 ? RTGS_WAVES_PER_SIMD_SH : RTGS_WAVES_PER_SIMD)
                                     : (!kBig && kSplit == 1 && kK == RTGS_MAX_DEPTH ? RTGS_WAVES_PER_SIMD_MAIN
@@ -654,6 +674,13 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   for (int k = 0; k < kWn; ++k) wexp[k] = 0.f;
   [[maybe_unused]] float* const s_wl = s_w + tid;
   constexpr bool kHorizon = RTGS_HORIZON != 0 && kK == RTGS_MAX_DEPTH;
+  static_assert(!kCut || (kSplit == 1 && kK == RTGS_MAX_DEPTH), "traversal cut: one-wave full-list form only");
+  constexpr int kChunksMax = kListCap / kWave;
+  __shared__ float s_smin[kCut ? kWaves * kChunksMax : 1];   // per wave: suffix minima of the chunks' distance bounds
+  [[maybe_unused]] float T_in = 1.f;                            // attenuation this call starts from
+  if constexpr (kCut) {
+    if ((a.flags & RTGS_TRACE_RESUME) && in_img) T_in = a.att[(size_t)pi * a.height + pj];
+  }
   constexpr bool kLookahead = RTGS_LOOKAHEAD == 2 || (RTGS_LOOKAHEAD == 1 && kBig);
   constexpr int kTier = (kLdsW && RTGS_TIER > 0 && RTGS_TIER < kK) ? RTGS_TIER : kK;
   [[maybe_unused]] bool tier_short = kTier < kK;   // wave-uniform: slot kTier-1 still empty in every lane
@@ -877,8 +904,45 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
         int g, gnext = -1;
         float4 wb, wbnext = make_float4(kInf, kInf, -kInf, -kInf);
         float tm, tmnext = 0.f;
+        // (only rounds of at least kCutMinChunks chunks are worth it: the check costs about as much as
+        // five candidates, and c3-sized tiles see two or three chunks in all)
+        constexpr int kCutMinChunks = 4;
+        [[maybe_unused]] const bool cut_round = kCut && total > (kCutMinChunks - 1) * kWave;
+        if (cut_round) {
+          // suffix minima of the distance bounds over this round's chunks (bounds are >= 0: their
+          // bits order like the floats)
+          unsigned run = kEmpty;
+          for (int c = ((total - 1) / kWave) * kWave; c >= 0; c -= kWave) {
+            int gq; float4 wq; float tq;
+            fetch(c, gq, wq, tq);
+            run = min(run, wave_umin(gq >= 0 ? __float_as_uint(tq) : kEmpty));
+            if (lane == 0) s_smin[wave * kChunksMax + c / kWave] = __uint_as_float(run);
+          }
+        }
         fetch(0, g, wb, tm);
         for (int c = 0; c < total; c += kWave) {
+          if (cut_round && c > 0 && (c & kWave) == 0 && total - c > kWave) {   // every other chunk
+            // attenuation through the entries nearer than everything still to come, as the
+            // compositing loop will form it (same operations in the same order)
+            const unsigned bnd = __float_as_uint(__builtin_amdgcn_readfirstlane(s_smin[wave * kChunksMax + c / kWave]));
+            float Tp = T_in;
+            int nh = 0;
+            unsigned prev = 0u;
+#pragma unroll
+            for (int k = 0; k < kK; ++k) {
+              const unsigned tb = key[k];
+              const bool fin = tb < bnd;                       // final: nothing to come can precede it
+              const bool valid = fin && tb != prev && nh < a.depth;
+              prev = tb;
+              if (wave_any(valid && !(Tp < a.t_cutoff))) {
+                const float op = fin ? colop[(kidx[k] >> kSlotBits)].w : 0.f;
+                const float alpha = op * expf(s_wl[(kidx[k] & 15u) * kBlock] - 3.0f);
+                if (valid && !(Tp < a.t_cutoff)) { Tp *= 1.0f - alpha; ++nh; }
+              }
+            }
+            const bool dead = !in_img || Tp < a.t_cutoff || nh == a.depth;
+            if (!wave_any(!dead)) break;                       // the ballot: nothing left for this tile here
+          }
           const bool pass = wb.x <= wXhi && wb.z >= wXlo && wb.y <= wYhi && wb.w >= wYlo;
           unsigned long long m = __ballot(pass);
           [[maybe_unused]] const unsigned long long m_all = m;
@@ -899,13 +963,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
             // reduction per 64 candidates; the image does not depend on it (such a candidate would
             // fail `kn < key[kK-1]` in every lane).  Scenes with large background Gaussians
             // (capture-like, tools/cap_sweep.py) lose most of their candidates here.
-            unsigned h = in_img ? key[kK - 1] : 0u;       // t1 bits; +inf while the list is not full
-            h = max(h, (unsigned)__builtin_amdgcn_update_dpp(0, (int)h, 0xB1, 0xF, 0xF, false));    // quad_perm 1,0,3,2
-            h = max(h, (unsigned)__builtin_amdgcn_update_dpp(0, (int)h, 0x4E, 0xF, 0xF, false));    // quad_perm 2,3,0,1
-            h = max(h, (unsigned)__builtin_amdgcn_update_dpp(0, (int)h, 0x141, 0xF, 0xF, false));   // row_half_mirror
-            h = max(h, (unsigned)__builtin_amdgcn_update_dpp(0, (int)h, 0x140, 0xF, 0xF, false));   // row_mirror
-            const unsigned hz = max(max((unsigned)__builtin_amdgcn_readlane((int)h, 0), (unsigned)__builtin_amdgcn_readlane((int)h, 16)),
-                                    max((unsigned)__builtin_amdgcn_readlane((int)h, 32), (unsigned)__builtin_amdgcn_readlane((int)h, 48)));
+            const unsigned hz = wave_umax(in_img ? key[kK - 1] : 0u);   // t1 bits; +inf while a list is not full
             // (evaluated even while hz is still +inf: this chunk's loads are all consumed before
             // the next chunk's are issued, so nothing inside the candidate loop waits for memory)
             m &= __ballot(tm < __uint_as_float(min(hz, kEmpty)) || hz >= kEmpty);
@@ -1393,13 +1451,17 @@ static int trace_impl(const RtgsScene* scene, const RtgsCamera* cam, const RtgsT
   if (params->flags & RTGS_TRACE_SPLIT_ON) split = true;
   if (params->flags & RTGS_TRACE_SPLIT_OFF) split = false;
   if (params->depth == 1) split = false;
+  // the cut-off's traversal cut has its own instantiation of the one-wave full-list form
+  const bool cut = RTGS_CUT_TRAVERSAL != 0 && params->t_cutoff > 0.f && params->depth > 1;
   if (a.idx_bits > 17) split = false;   // two-wave entries: rank | index | 5 slot bits in 32; 10 rank bits need n <= 131072
 #define RTGS_LAUNCH(HAS_SH, BIG, K, SPLIT)                                                         \
   hipLaunchKernelGGL((k_trace<HAS_SH, BIG, K, SPLIT>), dim3(local), dim3(kTraceBlock * SPLIT), 0, s, a, \
                      bbox, slab_bbox, super_bbox, rec, tail, tmin, colop, sh)
 #define RTGS_LAUNCH_K(HAS_SH, BIG)                                                  \
   do {                                                                              \
-    if (params->depth == 1) RTGS_LAUNCH(HAS_SH, BIG, 1, 1);                         \
+    if (cut) hipLaunchKernelGGL((k_trace<HAS_SH, BIG, RTGS_MAX_DEPTH, 1, true>), dim3(local), dim3(kTraceBlock), 0, s, a, \
+                                bbox, slab_bbox, super_bbox, rec, tail, tmin, colop, sh);                                \
+    else if (params->depth == 1) RTGS_LAUNCH(HAS_SH, BIG, 1, 1);                    \
     else if (split) RTGS_LAUNCH(HAS_SH, BIG, RTGS_MAX_DEPTH, 2);                    \
     else RTGS_LAUNCH(HAS_SH, BIG, RTGS_MAX_DEPTH, 1);                               \
   } while (0)

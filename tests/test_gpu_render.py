@@ -187,6 +187,38 @@ def test_transmittance_cutoff_matches_the_oracle(name, cut):
         assert np.abs(got - full["sample"]).max() > 1e-3
 
 
+@pytest.mark.parametrize("sh", [False, True])
+def test_cutoff_ends_traversal_on_a_dense_opaque_scene(sh):
+    # with t_cutoff > 0 the kernel also stops a tile's TRAVERSAL once every ray is terminated behind
+    # entries that nothing still to come can precede (k_trace<..., kCut>): many chunks per tile, rays
+    # that die after 2-4 hits.  Pixels, attenuation and ray.start must still equal the oracle's
+    # compositing rule, at full depth and at a shallow one, whole and sharded.
+    from oracle import c_oracle
+    arrays = synthetic.make_scene(30_000, 16 / 9, 4321, sh=sh)
+    arrays["scale"] = (arrays["scale"] * np.float32(2.2)).astype(np.float32)
+    arrays["opacity"] = (0.75 + 0.2 * arrays["opacity"]).astype(np.float32)
+    cam = synthetic.bench_camera(160, 90)
+    rng = np.random.default_rng(5)
+    pix = np.stack([rng.integers(0, 160, 2500), rng.integers(0, 90, 2500)], axis=-1).astype(np.int32)
+    for depth, cut in ((16, 0.05), (6, 0.3)):
+        _, _, tr = U.build(arrays, cam)
+        tr.sample_all(depth, t_cutoff=cut)
+        torch.cuda.synchronize()
+        want = c_oracle.render(arrays, cam, depth, pix, t_cutoff=cut)
+        full = c_oracle.render(arrays, cam, depth, pix)
+        assert (want["hits"] < full["hits"]).mean() > 0.5            # most rays are cut short
+        U.assert_parity(U.at(tr.sample_buf, pix), want, f"dense scene depth {depth} cut {cut}")
+        solid = ~want["fragile"]
+        assert np.abs(U.at(tr.attenuation_buf, pix) - want["attenuation"])[solid].max() <= U.PIXEL_TOL
+        start = U.at(tr.camera.cam_ray_field.start, pix)
+        assert (np.isfinite(start) == np.isfinite(want["start"]))[solid].all()
+        whole = tr.sample_buf.clone()
+        tr.clear_sample()
+        for r in range(3):
+            tr.trace(depth, t_cutoff=cut, tile_first=r, tile_step=3)
+        assert torch.equal(tr.sample_buf, whole)
+
+
 def test_exact_ties_do_not_use_up_peels_at_shallow_depth():
     # in the one-pass list an exact t1 tie occupies a slot; with depth < 16 the kernel
     # must keep walking its 16 slots until `depth` DISTINCT entry distances are composited, as the
