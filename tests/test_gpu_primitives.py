@@ -213,6 +213,51 @@ def test_ply_sh_layouts_and_crlf_header(tmp_path):
         rtgs.Scene().load_file(path, sh_layout="transposed")
 
 
+def test_ply_ingest_at_capture_scale_renders_like_its_arrays(tmp_path):
+    # SURVEY 8(f)-2 at the size of the reference's use case (truck.ply, ~150 k Gaussians,
+    # docs/source/get-started.md:64-74): an INRIA-layout binary PLY (raw log-scales, logit opacities,
+    # wxyz quaternions, f_dc, channel-major f_rest) written here, loaded through Scene.load_file
+    # (scene.py:95-114: activations, normalisation, wxyz -> xyzw) and rendered; must equal the scene
+    # built directly from the post-activation arrays, and the C oracle on sampled pixels
+    from oracle import c_oracle
+    from rtgs import synthetic
+    n, w, h = 60_000, 240, 135
+    arrays = synthetic.make_capture_scene(n, w / h, 99)
+    rng = np.random.default_rng(8)
+    sh = (rng.random((n, 15, 3)) * 0.1 - 0.05).astype(np.float32)
+    q = arrays["rotation"] * rng.uniform(0.5, 2.0, (n, 1)).astype(np.float32)      # the loader normalises
+    raw = np.concatenate([
+        arrays["position"], np.zeros((n, 3), np.float32),
+        np.log(arrays["color"] / (1 - arrays["color"])),                              # f_dc: sigmoid^-1
+        sh.transpose(0, 2, 1).reshape(n, 45),                                         # channel-major f_rest
+        np.log(arrays["opacity"] / (1 - arrays["opacity"]))[:, None],
+        np.log(arrays["scale"] / np.float32(1.5)),                                    # load_file(scale=1.5)
+        q[:, [3, 0, 1, 2]]], axis=1).astype("<f4")
+    names = ["x", "y", "z", "nx", "ny", "nz", "f_dc_0", "f_dc_1", "f_dc_2"] + [f"f_rest_{i}" for i in range(45)] + \
+            ["opacity", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2", "rot_3"]
+    header = "\n".join(["ply", "format binary_little_endian 1.0", f"element vertex {n}"] +
+                       [f"property float {nm}" for nm in names] + ["end_header"]) + "\n"
+    path = tmp_path / "capture.ply"
+    path.write_bytes(header.encode() + raw.tobytes())
+    scene = rtgs.Scene()
+    scene.load_file(path, 1.5)
+    f = scene.gaussian_field
+    assert f.n == n
+    for name, want in (("position", arrays["position"]), ("rotation", arrays["rotation"]), ("scale", arrays["scale"]),
+                       ("color", arrays["color"]), ("opacity", arrays["opacity"]), ("sh", sh)):
+        assert np_(getattr(f, name)) == pytest.approx(want, rel=3e-5, abs=3e-6), name
+    cam = synthetic.bench_camera(w, h)
+    camera = rtgs.Camera(cam["position"], cam["rotation"], (w, h), (cam["fx"], cam["fy"]))
+    tracer = rtgs.RayTracer((w, h), scene, camera)
+    tracer.sample_all(16)
+    torch.cuda.synchronize()
+    loaded = {k: np_(getattr(f, k)) for k in ("position", "rotation", "scale", "color", "opacity", "sh")}
+    pix = np.stack([rng.integers(0, w, 1500), rng.integers(0, h, 1500)], axis=-1).astype(np.int32)
+    want = c_oracle.render(loaded, cam, 16, pix)
+    U.assert_parity(U.at(tracer.sample_buf, pix), want, "PLY scene at capture scale")
+    assert want["hits"].mean() > 4
+
+
 def test_accelerated_scene_hit_equals_brute_force_bit_for_bit():
     # the slab-box structure (what the reference's BVH is to Scene.hit, scene.py:162-450) only culls
     # Gaussians a ray cannot hit: indices AND distances must equal the brute-force kernel's exactly,
