@@ -839,18 +839,17 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
         int gbase[kExpand];
 #pragma unroll
         for (int q = 0; q < kExpand; ++q) {
-          gb[q] = make_float4(kInf, kInf, -kInf, -kInf);
-          gbase[q] = 0;
-          if (pos + q < pend) {
-            gbase[q] = __builtin_amdgcn_readfirstlane((int)s_slab[pos + q]) * kSlab;
-            if (gbase[q] + lane < a.n) gb[q] = bbox[gbase[q] + lane];
-          }
+          // branch-free (clamped slab and lane: a repeated slab is not consumed below, lanes past n
+          // are not kept), so that the loads really are in flight together
+          gbase[q] = __builtin_amdgcn_readfirstlane((int)s_slab[min(pos + q, pend - 1)]) * kSlab;
+          gb[q] = bbox[(unsigned)min(gbase[q] + lane, a.n - 1)];
         }
         bool full = false;
 #pragma unroll
         for (int q = 0; q < kExpand; ++q) {
           if (pos < pend && !full) {
-            const bool keep = gb[q].x <= mXhi && gb[q].z >= mXlo && gb[q].y <= mYhi && gb[q].w >= mYlo;
+            const bool keep = gb[q].x <= mXhi && gb[q].z >= mXlo && gb[q].y <= mYhi && gb[q].w >= mYlo &&
+                              gbase[q] + lane < a.n;
             const unsigned long long gm = __ballot(keep);
             const int c = __popcll(gm);
             if (rcnt + c > kRegionCap) {
