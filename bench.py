@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--config", default="c3", help="c2 | c3 | c5 (SURVEY.md 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scene-hit", action="store_true", help="skip the arbitrary-ray Scene.hit figure")
+    ap.add_argument("--no-secondary", action="store_true", help="headline only: no Scene.hit and no t_cutoff "
+                    "figures (profiling runs: their kernels would be averaged into k_trace's counters)")
     ap.add_argument("--cpu-rays", type=int, default=256, help="rays of the NumPy baseline sample")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo "
                     "only for functional rehearsal of the N > 1 path)")
@@ -283,7 +285,7 @@ def main():
         }
         line["secondary"] = {"closest_hit_queries_per_s": mrays * 1e6 * cfg.depth,
                              "frame_ms_median_hip_events": frame_ms_median}
-        if world == 1:
+        if world == 1 and not args.no_secondary:
             # the transmittance cut-off (extension, off in the headline: the reference has none)
             cut = TileParallelRenderer(scene, camera, depth=cfg.depth, rank=0, world=1, t_cutoff=5e-5)
             for _ in range(3):
@@ -294,7 +296,7 @@ def main():
                 cut.render_frame()
             torch.cuda.synchronize()
             line["secondary"]["frame_ms_with_t_cutoff_5e-5"] = (time.perf_counter() - t0) / 20 * 1e3
-        if world == 1 and not args.no_scene_hit:
+        if world == 1 and not args.no_scene_hit and not args.no_secondary:
             line["secondary"]["scene_hit_960x540"] = closest_hit_rates(scene, cam)
         if verified is not None:
             line["verified"] = verified

@@ -6,7 +6,7 @@ python -m pytest $R/tests -x -q -m gpu -k "$K" > $R/gpurun_out/q_${TAG}_tests.lo
 tail -4 $R/gpurun_out/q_${TAG}_tests.log
 [ $rc -ne 0 ] && exit $rc
 for c in c3 c5 c2; do
-  python $R/bench.py --config $c --steps 100 --warmup 10 --no-cpu-baseline --no-scene-hit 2>/dev/null | tail -1 > $R/gpurun_out/q_${TAG}_$c.json
+  python $R/bench.py --config $c --steps 100 --warmup 10 --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 > $R/gpurun_out/q_${TAG}_$c.json
   python - <<PY
 import json
 d=json.loads(open("$R/gpurun_out/q_${TAG}_$c.json").read())
