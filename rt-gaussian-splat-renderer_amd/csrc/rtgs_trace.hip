@@ -617,6 +617,12 @@ __device__ __forceinline__ unsigned wave_umax(unsigned h) {
              max((unsigned)__builtin_amdgcn_readlane((int)h, 32), (unsigned)__builtin_amdgcn_readlane((int)h, 48)));
 }
 __device__ __forceinline__ unsigned wave_umin(unsigned h) { return ~wave_umax(~h); }
+// exp(w - 3) for the exponent w = delta/(4A) in [0, 3] of a hit (gaussian.py:197 at the chord midpoint): one
+// multiply-add and v_exp_f32 (2^x, 1 ulp) -- the argument is in [-4.33, 0], nowhere near the
+// denormal / overflow handling that libm's expf spends another eight instructions on
+__device__ __forceinline__ float exp_m3(float w) {
+  return __builtin_amdgcn_exp2f(fmaf(w, 1.4426950408889634f, -4.3280851226668902f));
+}
 // HIP's __any() goes through an int (v_cndmask 0/1 + v_cmp_ne): the ballot form is the compare itself
 __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 // Per-lane list of the RTGS_MAX_DEPTH smallest entry distances: three register arrays (t1 bits,
@@ -1090,7 +1096,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
               prev = tb;
               if (wave_any(valid && !(Tp < a.t_cutoff))) {
                 const float op = fin ? colop[(kidx[k] >> kSlotBits)].w : 0.f;
-                const float alpha = op * expf(s_wl[(kidx[k] & 15u) * kBlock] - 3.0f);
+                const float alpha = op * exp_m3(s_wl[(kidx[k] & 15u) * kBlock]);
                 if (valid && !(Tp < a.t_cutoff)) { Tp *= 1.0f - alpha; ++nh; }
               }
             }
@@ -1200,7 +1206,9 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
 #else
             const float t1 = (q2.w / (sqrtf(e) - bq)) * dlen;
 #endif
-            const bool cand = hit && t1 > start && t1 < kInf;  // scene.py:433
+            // scene.py:433: start < t1 < end, end = +inf for a camera ray (an overflowed t1 = +inf has the
+            // bits of an empty slot and fails the insertion test below by itself; NaN fails `>`)
+            const bool cand = hit && t1 > start;
             const unsigned kn = cand ? __float_as_uint(t1) : ~0u;
             const bool ins = kn < key[kK - 1];
             if (wave_any(ins)) {
@@ -1403,7 +1411,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
         }
         float wk;
         if constexpr (kLdsW) wk = wl[j]; else wk = wexp[k];
-        const float alpha = co.w * expf(wk - 3.0f);  // == exp(-d^T S^-1 d) at the chord midpoint
+        const float alpha = co.w * exp_m3(wk);  // == exp(-d^T S^-1 d) at the chord midpoint
         if (live) {
           const float wa = T * alpha;
           L0 += wa * co.x; L1 += wa * co.y; L2 += wa * co.z;
