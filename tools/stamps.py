@@ -57,10 +57,6 @@ for world in (1, 8):
     t0 = s[:, 0].min()
     print(f"world {world}: {len(s)} blocks; kernel span {(s[:,4].max()-t0)/100:.1f} us (100 MHz ticks?)")
     names = ["scan", "expand", "process", "composite"]
-    if "slabs" in dir():
-        z = slabs == 0
-        print(f"   tiles listing from a bin (no slab scanned): {z.mean():.1%}; mean scan ticks: binned {d[z,0].mean() if z.any() else 0:.0f}, scanning {d[~z,0].mean() if (~z).any() else 0:.0f}; "
-              f"mean expand ticks: binned {d[z,1].mean() if z.any() else 0:.0f}, scanning {d[~z,1].mean() if (~z).any() else 0:.0f}")
     for k, nme in enumerate(names):
         print(f"   {nme:10s} mean {d[:,k].mean():9.0f}  p50 {np.median(d[:,k]):9.0f}  p95 {np.percentile(d[:,k],95):9.0f} ticks")
     life = s[:, 4] - s[:, 0]
