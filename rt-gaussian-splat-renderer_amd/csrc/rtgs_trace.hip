@@ -481,7 +481,10 @@ __global__ __launch_bounds__(256) void k_super_bbox(int32_t nslabs, const float4
 // steps and rank-sorting its survivors -- a quarter of a k_trace workgroup's life at c3.
 // ------------------------------------------------------------------------------------
 constexpr int kBinCapMax = 1024;          // slabs a bin can list; more = overflow, the tiles fall back to scanning
-constexpr int kBinIters = 4;
+#ifndef RTGS_BIN_ITERS
+#define RTGS_BIN_ITERS 4
+#endif
+constexpr int kBinIters = RTGS_BIN_ITERS;
 
 __host__ __device__ inline int bin_stride_of(size_t nslabs) {
   const size_t c = nslabs < (size_t)kBinCapMax ? nslabs : (size_t)kBinCapMax;
