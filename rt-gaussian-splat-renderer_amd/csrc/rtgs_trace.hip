@@ -74,6 +74,9 @@ namespace {
 #ifndef RTGS_CUT_TRAVERSAL
 #define RTGS_CUT_TRAVERSAL 1   // t_cutoff > 0 also ends a tile's traversal (k_trace<..., kCut = true>)
 #endif
+#ifndef RTGS_COMPOSITE_EXIT
+#define RTGS_COMPOSITE_EXIT 1
+#endif
 #ifndef RTGS_SKIP_LOWER
 #define RTGS_SKIP_LOWER 1   // skip the insertion's lower half when no lane inserts there
 #endif
@@ -1129,7 +1132,9 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
             // reduction per 64 candidates; the image does not depend on it (such a candidate would
             // fail `kn < key[kK-1]` in every lane).  Scenes with large background Gaussians
             // (capture-like, tools/cap_sweep.py) lose most of their candidates here.
-            const unsigned hz = wave_umax(in_img ? key[kK - 1] : 0u);   // t1 bits; +inf while a list is not full
+            // (while some list is not full the horizon is +inf: one compare + ballot instead of the reduction)
+            const bool open_list = wave_any(in_img && key[kK - 1] >= kEmpty);
+            const unsigned hz = open_list ? kEmpty : wave_umax(in_img ? key[kK - 1] : 0u);   // t1 bits
             // (evaluated even while hz is still +inf: this chunk's loads are all consumed before
             // the next chunk's are issued, so nothing inside the candidate loop waits for memory)
             m &= __ballot(tm < __uint_as_float(min(hz, kEmpty)) || hz >= kEmpty);
@@ -1250,7 +1255,8 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
                 // lower half is untouched in the whole wave unless some lane has kn below key[kTier-1]:
                 // one compare + ballot skips it -- candidates arrive nearest first, so the later ones
                 // mostly land in the upper half (c3: 0.1634 -> 0.1551 ms).  Four blocks of four with a
-                // ballot each lose again (0.211: too many small basic blocks).
+                // ballot each lose again (0.211: too many small basic blocks), and three straight-line
+                // cases (short / both halves / upper only) make the register allocator spill 107 VGPRs.
                 const bool low = kTier == kK || tier_short || wave_any(kn < key[kTier - 1]);
                 if constexpr (kTier < kK) {
                   if (!tier_short) list_insert2<kTier, kK>(key, kidx, kn, pn);
@@ -1390,6 +1396,9 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
     // slots beyond the first `depth` only matter to lanes that dropped an exact t1 tie on the way
     // (the reference's peel loop peels on until `depth` DISTINCT entry distances are composited)
     if (k0 >= a.depth && !wave_any(nhit < a.depth && key[k0] < kEmpty)) break;
+#if RTGS_COMPOSITE_EXIT
+    if (k0 > 0 && !wave_any(key[k0] < kEmpty)) break;   // every list of the wave ends before this group
+#endif
     float4 cog[kGroup];
     [[maybe_unused]] float wl[kGroup];
 #pragma unroll
