@@ -1365,10 +1365,16 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   int lane_e = lane;
   asm volatile("" : "+v"(lane_e));
   const int pi_e = wi0 + (lane_e >> 3), pj_e = wj0 + (lane_e & 7);
-  const size_t pix = (size_t)pi_e * a.height + pj_e;
+  // The arguments the epilogue needs are read again from the kernarg segment behind a laundered
+  // pointer: kept in SGPRs from the prologue they cost ~20 of the 102 through the whole candidate
+  // loop (and that many v_writelane / v_readlane spills).
+  using KArgs = const TraceArgs __attribute__((address_space(4)));
+  KArgs* ea = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(ea));
+  const size_t pix = (size_t)pi_e * ea->height + pj_e;
   float T = 1.f;
 #if !RTGS_STAMPS
-  if ((a.flags & RTGS_TRACE_RESUME) && in_img) T = a.att[pix];
+  if ((ea->flags & RTGS_TRACE_RESUME) && in_img) T = ea->att[pix];
 #endif
   float L0 = 0.f, L1 = 0.f, L2 = 0.f;
   float Ysh[RTGS_SH_COEFFS];
@@ -1377,14 +1383,14 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
     const float cx = dcx * il, cy = dcy * il, cz = -il;
     float rcf[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) rcf[k] = a.pose ? (float)a.pose->rc[k] : a.rc[k];
+    for (int k = 0; k < 9; ++k) rcf[k] = ea->pose ? (float)ea->pose->rc[k] : ea->rc[k];
     float wx = rcf[0] * cx + rcf[1] * cy + rcf[2] * cz;
     float wy = rcf[3] * cx + rcf[4] * cy + rcf[5] * cz;
     float wz = rcf[6] * cx + rcf[7] * cy + rcf[8] * cz;
     const float in = 1.0f / sqrtf(wx * wx + wy * wy + wz * wz);  // gaussian.py:200
     sh_basis(wx * in, wy * in, wz * in, Ysh);
   }
-  [[maybe_unused]] const unsigned idx_mask = kSplit == 2 ? (1u << a.idx_bits) - 1u : ~0u;
+  [[maybe_unused]] const unsigned idx_mask = kSplit == 2 ? (1u << ea->idx_bits) - 1u : ~0u;
   int nhit = 0;
   float last_t = 0.f;
   unsigned prev_tbits = 0u;
@@ -1395,7 +1401,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
     if (done) break;
     // slots beyond the first `depth` only matter to lanes that dropped an exact t1 tie on the way
     // (the reference's peel loop peels on until `depth` DISTINCT entry distances are composited)
-    if (k0 >= a.depth && !wave_any(nhit < a.depth && key[k0] < kEmpty)) break;
+    if (k0 >= ea->depth && !wave_any(nhit < ea->depth && key[k0] < kEmpty)) break;
 #if RTGS_COMPOSITE_EXIT
     if (k0 > 0 && !wave_any(key[k0] < kEmpty)) break;   // every list of the wave ends before this group
 #endif
@@ -1419,11 +1425,11 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
         const unsigned gi = kLdsW ? (kidx[k] >> kSlotBits) & idx_mask : kidx[k];
         // an exact repeat of the previous entry distance is what the reference's strict
         // `t1 > ray.start` drops (scene.py:433 after ray_tracer.py:101)
-        const bool valid = tbits < kEmpty && tbits != prev_tbits && nhit < a.depth;
+        const bool valid = tbits < kEmpty && tbits != prev_tbits && nhit < ea->depth;
         // transmittance cut-off (extension, off by default): a ray below it stops compositing
         // -- as if it had missed, ray.start = +inf -- and a wave ballot ends the loop
-        const bool live = valid && !(a.t_cutoff > 0.f && T < a.t_cutoff);
-        if (a.t_cutoff > 0.f && !wave_any(live)) { done = true; continue; }
+        const bool live = valid && !(ea->t_cutoff > 0.f && T < ea->t_cutoff);
+        if (ea->t_cutoff > 0.f && !wave_any(live)) { done = true; continue; }
         prev_tbits = tbits;
         float4 co = cog[j];
         if (kHasSh) {
@@ -1451,12 +1457,12 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
     }
   }
 
-  if (a.flags & RTGS_TRACE_COMPACT) {
-    float* o = a.sample + ((size_t)ltile * kTile * kTile + (size_t)(pi_e - mi0) * kTile + (pj_e - mj0)) * 3;
+  if (ea->flags & RTGS_TRACE_COMPACT) {
+    float* o = ea->sample + ((size_t)ltile * kTile * kTile + (size_t)(pi_e - mi0) * kTile + (pj_e - mj0)) * 3;
     *reinterpret_cast<Rgb*>(o) = Rgb{L0, L1, L2};   // one 12-B store per lane
   } else if (in_img) {
-    float* o = a.sample + pix * 3;
-    if (a.flags & RTGS_TRACE_ACCUMULATE) {
+    float* o = ea->sample + pix * 3;
+    if (ea->flags & RTGS_TRACE_ACCUMULATE) {
       const Rgb old = *reinterpret_cast<const Rgb*>(o);
       L0 += old.r; L1 += old.g; L2 += old.b;
     }
@@ -1464,8 +1470,8 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   }
 #if RTGS_STAMPS
   st[4] = __builtin_amdgcn_s_memtime();
-  if (tid == 0 && a.att) {
-    unsigned long long* sp = reinterpret_cast<unsigned long long*>(a.att) + (size_t)blockIdx.x * 14;
+  if (tid == 0 && ea->att) {
+    unsigned long long* sp = reinterpret_cast<unsigned long long*>(ea->att) + (size_t)blockIdx.x * 14;
     sp[10] = t_exp; sp[11] = t_bar; sp[12] = t_merge; sp[13] = (unsigned long long)c_rounds;
     for (int k = 0; k < 5; ++k) sp[k] = st[k];
     sp[8] = rt0; sp[9] = __builtin_amdgcn_s_memrealtime();
@@ -1479,10 +1485,10 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
 #endif
   if (in_img) {
 #if !RTGS_STAMPS
-    if (a.att) a.att[pix] = T;
+    if (ea->att) ea->att[pix] = T;
 #endif
     // ray_tracer.py:99-104: start = t1 + EPS after a hit, +inf after a miss
-    if (a.start) a.start[pix * a.start_stride] = (nhit == a.depth) ? last_t + 1e-8f : kInf;
+    if (ea->start) ea->start[pix * ea->start_stride] = (nhit == ea->depth) ? last_t + 1e-8f : kInf;
   }
 }
 
