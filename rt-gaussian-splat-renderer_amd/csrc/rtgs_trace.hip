@@ -484,6 +484,9 @@ __global__ __launch_bounds__(256) void k_super_bbox(int32_t nslabs, const float4
 // steps and rank-sorting its survivors -- a quarter of a k_trace workgroup's life at c3.
 // ------------------------------------------------------------------------------------
 constexpr int kBinCapMax = 1024;          // slabs a bin can list; more = overflow, the tiles fall back to scanning
+#ifndef RTGS_BIN_GROUPS
+#define RTGS_BIN_GROUPS 4096   // 16-slab groups a supertile can keep in k_bin<true> (65 k slabs = 4 M Gaussians' worth);
+#endif                         // more = overflow, its tiles scan for themselves (1024 measures the same at c5)
 #ifndef RTGS_BIN_ITERS
 #define RTGS_BIN_ITERS 4
 #endif
@@ -503,7 +506,7 @@ __global__ __launch_bounds__(256) void k_bin(int32_t nslabs, const float4* __res
   __shared__ int s_id[kBinCapMax];
   __shared__ float s_key[kBinCapMax];
   __shared__ int s_wc[2][4];
-  constexpr int kGrpCap = 4096;                       // groups a supertile can keep (65 536 slabs = 4 M Gaussians' worth)
+  constexpr int kGrpCap = RTGS_BIN_GROUPS;
   __shared__ int s_grp[kGroups ? kGrpCap : 1];
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
   const int st = blockIdx.x;
