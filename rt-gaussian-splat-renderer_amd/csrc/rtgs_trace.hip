@@ -77,6 +77,9 @@ namespace {
 #ifndef RTGS_COMPOSITE_EXIT
 #define RTGS_COMPOSITE_EXIT 1
 #endif
+#ifndef RTGS_MED3
+#define RTGS_MED3 1   // keys move by v_med3_u32 (the list is sorted): 16 instead of 32 selects; c3 0.1506 -> 0.1388 ms
+#endif
 #ifndef RTGS_SKIP_LOWER
 #define RTGS_SKIP_LOWER 1   // skip the insertion's lower half when no lane inserts there
 #endif
@@ -687,11 +690,20 @@ __device__ __forceinline__ void list_insert2(unsigned (&kt)[kK], unsigned (&kp)[
   for (int k = kB; k < kHi; ++k) lt[k - kB] = tn < kt[k];
 #pragma unroll
   for (int k = kHi - 1; k > kB; --k) {
+#if RTGS_MED3
+    // the list is sorted, so the new key of slot k is the median of (left neighbour, itself, new key)
+    kt[k] = max(min(kt[k - 1], kt[k]), min(max(kt[k - 1], kt[k]), tn));
+#else
     kt[k] = lt[k - 1 - kB] ? kt[k - 1] : (lt[k - kB] ? tn : kt[k]);
+#endif
     kp[k] = lt[k - 1 - kB] ? kp[k - 1] : (lt[k - kB] ? pn : kp[k]);
   }
   if constexpr (kLo == 0) {
+#if RTGS_MED3
+    kt[0] = min(kt[0], tn);
+#else
     kt[0] = lt[0] ? tn : kt[0];
+#endif
     kp[0] = lt[0] ? pn : kp[0];
   }
 }
