@@ -120,6 +120,9 @@ namespace {
 #ifndef RTGS_EXPAND_BIG
 #define RTGS_EXPAND_BIG 4
 #endif
+#ifndef RTGS_GROUP_SH
+#define RTGS_GROUP_SH 2   // SH kernels of every size
+#endif
 #ifndef RTGS_GROUP_BIG
 #define RTGS_GROUP_BIG 2   // c5: register pressure of the SH variant decides (8: 1.67 ms, 4: 1.53-1.60, 2: 1.54)
 #endif
@@ -1409,7 +1412,10 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   int nhit = 0;
   float last_t = 0.f;
   unsigned prev_tbits = 0u;
-  constexpr int kGroup = TN::kGroup < kK ? TN::kGroup : kK;   // colour/opacity gathers issued together
+  // colour/opacity gathers issued together; the SH variants carry 15 basis values per lane and keep
+  // two in flight whatever the scene size (four spilled 56 VGPRs in the <= 4096-slab SH kernel)
+  constexpr int kGroupN = kHasSh && TN::kGroup > RTGS_GROUP_SH ? RTGS_GROUP_SH : TN::kGroup;
+  constexpr int kGroup = kGroupN < kK ? kGroupN : kK;
   bool done = false;
 #pragma unroll
   for (int k0 = 0; k0 < kK; k0 += kGroup) {
@@ -1449,13 +1455,37 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
         float4 co = cog[j];
         if (kHasSh) {
           if (live) {   // (gathering for every slot, valid or not, to batch the loads: 2.24 vs 2.08 ms on c5)
+            // (records padded to 192 or 256 B and 16-B aligned: c3 + SH 0.310 -> 0.333 / 0.381 ms --
+            // the gather is bound by the lines it touches.  SH per (wave, insertion event) through
+            // scalar loads instead -- a wave logs ~23 events while its lanes composite ~14 entries
+            // each -- with the weights T alpha handed over in the exponent slots: c3 + SH 0.289 ->
+            // 0.317, c5 1.30 -> 1.99: one event's 45 coefficients at a time leaves the scalar-load
+            // latency exposed, the log's LDS costs c5 a workgroup per CU, and 23 x 68 v_pk_fma_f32
+            // per wave is 1.6 x the arithmetic of 14 x 68.)
             const float* sp = sh + (size_t)gi * (RTGS_SH_COEFFS * 3);
+#if RTGS_SH_ABLATE == 1   // timing only: the loads without the arithmetic
+#pragma unroll
+            for (int q = 0; q < RTGS_SH_COEFFS; ++q) {
+              float v0 = sp[3 * q + 0], v1 = sp[3 * q + 1], v2 = sp[3 * q + 2];
+              asm volatile("" :: "v"(v0), "v"(v1), "v"(v2));
+            }
+#elif RTGS_SH_ABLATE == 2   // timing only: the arithmetic without the loads
+            float f0 = co.x, f1 = co.y, f2 = co.z;
+#pragma unroll
+            for (int q = 0; q < RTGS_SH_COEFFS; ++q) {
+              asm volatile("" : "+v"(f0), "+v"(f1), "+v"(f2));
+              co.x += Ysh[q] * f0;
+              co.y += Ysh[q] * f1;
+              co.z += Ysh[q] * f2;
+            }
+#else
 #pragma unroll
             for (int q = 0; q < RTGS_SH_COEFFS; ++q) {
               co.x += Ysh[q] * sp[3 * q + 0];
               co.y += Ysh[q] * sp[3 * q + 1];
               co.z += Ysh[q] * sp[3 * q + 2];
             }
+#endif
           }
         }
         float wk;

@@ -39,6 +39,8 @@ CONFIGS = {
     "c5": Config("c5", 1_000_000, 3840, 2160, 1005, sh=True),
     # not a BASELINE config: c3's size with capture-like statistics, see make_capture_scene
     "cap": Config("cap", 100_000, 1920, 1080, 1013),
+    # not a BASELINE config: c3 with degree-3 SH (the kernel a PLY capture with f_rest takes)
+    "c3sh": Config("c3sh", 100_000, 1920, 1080, 1003, sh=True),
 }
 
 

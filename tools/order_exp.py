@@ -49,7 +49,8 @@ else:
         compact = b.alloc(per, T, T, 3)
         orders = {
             "none": None,
-            "centre prior": cost_sorted_order(cfg.width, cfg.height, T, 0, world),
+            "centre prior": cost_sorted_order(cfg.width, cfg.height, T, 0, world, "centre"),
+            "xcd wedges": cost_sorted_order(cfg.width, cfg.height, T, 0, world, "wedge"),
             "measured desc": np.argsort(-life, kind="stable"),
             "measured snake": snake(np.argsort(-life, kind="stable")),
             "insertions desc": np.argsort(-ins, kind="stable"),
