@@ -140,6 +140,18 @@ int32_t rtgs_tile_size(void);
 int32_t rtgs_num_tiles(int32_t width, int32_t height);
 int32_t rtgs_num_local_tiles(int32_t width, int32_t height, int32_t tile_first, int32_t tile_step);
 
+/* Host only: fills order[0 .. rtgs_num_local_tiles()) (HOST memory) with a launch order for
+ * RtgsTraceParams.tile_order (copy it to the device once per (size, shard)); returns the count or
+ * RTGS_EINVAL.  Scheduling only -- the pixels do not depend on it.
+ *   kind 0  most central tile first: workgroups b, b+256, ... share a CU, so every CU gets one tile
+ *           of each cost class (perspective piles depth complexity up in the centre);
+ *   kind 1  the same inside 8 equal-count image wedges, dealt out so that workgroup b -- which the
+ *           dispatcher hands to XCD b % 8 -- renders a tile of wedge b % 8: each XCD's 4 MiB L2 then
+ *           serves the Gaussians of one eighth of the screen (k_trace c3 0.139 -> 0.135 ms, with SH
+ *           0.310 -> 0.289).  What rtgs.RayTracer uses. */
+int32_t rtgs_launch_order(int32_t width, int32_t height, int32_t tile_first, int32_t tile_step, int32_t kind,
+                          int32_t* order);
+
 /* RayTracer.sample_step x depth (ray_tracer.py:39-54, 79-104) with Scene.hit's closest-hit
  * semantics (scene.py:433-437), Gaussian.hit (gaussian.py:203-230), Gaussian.eval / eval_sh
  * (gaussian.py:140-201) and the clear_attenuation + generate_ray_field of step 0, in one pass:

@@ -41,6 +41,9 @@
 #include <string.h>
 
 #include <type_traits>
+#include <vector>
+#include <algorithm>
+#include <cmath>
 
 namespace rtgs {
 namespace {
@@ -1619,6 +1622,44 @@ int32_t rtgs_num_local_tiles(int32_t width, int32_t height, int32_t tile_first, 
   const int32_t total = rtgs_num_tiles(width, height);
   if (tile_step <= 0 || tile_first < 0 || tile_first >= total) return 0;
   return (total - tile_first + tile_step - 1) / tile_step;
+}
+
+// Host only.  kind 0: most central tile first; kind 1: one image wedge per XCD (see rtgs_hip.h).
+int32_t rtgs_launch_order(int32_t width, int32_t height, int32_t tile_first, int32_t tile_step, int32_t kind,
+                          int32_t* order) {
+  const int32_t n = rtgs_num_local_tiles(width, height, tile_first, tile_step);
+  if (!order || n <= 0 || (kind != 0 && kind != 1)) return RTGS_EINVAL;
+  const int tx = (width + kTile - 1) / kTile;
+  std::vector<double> centr(n), angle(n);
+  for (int32_t l = 0; l < n; ++l) {
+    const int t = tile_first + l * tile_step;
+    const double cx = ((t % tx) + 0.5) * kTile - 0.5 * width, cy = ((t / tx) + 0.5) * kTile - 0.5 * height;
+    centr[l] = std::max(std::fabs(cx) / (0.5 * width), std::fabs(cy) / (0.5 * height));
+    angle[l] = std::atan2(cy, cx);
+  }
+  std::vector<int32_t> by(n);
+  for (int32_t l = 0; l < n; ++l) by[l] = l;
+  constexpr int kXcds = 8;
+  if (kind == 0 || n < 8 * kXcds) {
+    std::stable_sort(by.begin(), by.end(), [&](int32_t p, int32_t q) { return centr[p] < centr[q]; });
+    memcpy(order, by.data(), sizeof(int32_t) * (size_t)n);
+    return n;
+  }
+  // equal-count wedges by angle rank, most central first inside a wedge, then dealt out round-robin:
+  // position kXcds * i + x holds the i-th tile of wedge x
+  std::stable_sort(by.begin(), by.end(), [&](int32_t p, int32_t q) { return angle[p] < angle[q]; });
+  std::vector<std::vector<int32_t>> wedge(kXcds);
+  for (int32_t r = 0; r < n; ++r) wedge[(int)(((int64_t)r * kXcds) / n)].push_back(by[r]);
+  size_t rows = 0;
+  for (auto& wv : wedge) {
+    std::stable_sort(wv.begin(), wv.end(), [&](int32_t p, int32_t q) { return centr[p] < centr[q]; });
+    rows = std::max(rows, wv.size());
+  }
+  int32_t pos = 0;
+  for (size_t i = 0; i < rows; ++i)
+    for (int x = 0; x < kXcds; ++x)
+      if (i < wedge[x].size()) order[pos++] = wedge[x][i];
+  return pos;
 }
 
 // workspace: [bbox nn x float4][records nn x 16 float][tails nn x 8 float][distance bounds nn float][slab bounds][group bounds][slab depth keys]

@@ -56,6 +56,7 @@ PROTOTYPES = {
     "rtgs_tile_size": (c_int32, []),
     "rtgs_num_tiles": (c_int32, [c_int32, c_int32]),
     "rtgs_num_local_tiles": (c_int32, [c_int32, c_int32, c_int32, c_int32]),
+    "rtgs_launch_order": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "rtgs_trace": (c_int32, [POINTER(RtgsScene), POINTER(RtgsCamera), POINTER(RtgsTraceParams),
                              c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_int32,
                              c_void_p]),

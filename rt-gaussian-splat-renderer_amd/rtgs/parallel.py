@@ -44,26 +44,19 @@ def cost_sorted_order(width: int, height: int, tile: int, first: int, step: int,
     of it, while every XCD still gets the same mix of heavy central and light border tiles.
     Measured on MI355X (k_trace): c3 0.140 -> 0.137 ms, c3 + SH 0.310 -> 0.289, c5 1.318 -> 1.301.
     Vertical strips or 4 x 2 blocks per XCD lose 20 % (the central regions are heavier); Morton
-    order or radial bands inside a wedge lose 3-18 % against most-central-first."""
+    order or radial bands inside a wedge lose 3-18 % against most-central-first.
+    Computed by the library (rtgs_launch_order) so that C callers get the same order."""
     import numpy as np
-    tx, ty = (width + tile - 1) // tile, (height + tile - 1) // tile
-    t = first + step * np.arange(local_tile_count(tx * ty, first, step) if step > 0 else 0)
-    cx, cy = (t % tx + 0.5) * tile, (t // tx + 0.5) * tile
-    m = np.maximum(np.abs(cx - width / 2) / (width / 2), np.abs(cy - height / 2) / (height / 2))
-    if mode != "wedge" or len(t) < 64:
-        return np.argsort(m, kind="stable").astype(np.int32)
-    nx = 8   # XCDs
-    angle = np.arctan2(cy - height / 2, cx - width / 2)
-    rank = np.argsort(np.argsort(angle, kind="stable"), kind="stable")
-    wedge = (rank * nx) // len(t)                   # equal counts (+-1) by construction
-    groups = [np.flatnonzero(wedge == x) for x in range(nx)]
-    groups = [g[np.argsort(m[g], kind="stable")] for g in groups]
-    rows = max(len(g) for g in groups)
-    grid = np.full((rows, nx), -1, dtype=np.int64)
-    for x, g in enumerate(groups):
-        grid[:len(g), x] = g
-    out = grid.reshape(-1)
-    return out[out >= 0].astype(np.int32)
+    from . import _native as nat
+    assert tile == nat.tile_size()
+    n = local_tile_count(tiles_of(width, height, tile), first, step) if step > 0 else 0
+    out = np.empty(max(n, 0), dtype=np.int32)
+    if n > 0:
+        got = nat.lib().rtgs_launch_order(width, height, first, step, 1 if mode == "wedge" else 0,
+                                          out.ctypes.data)
+        nat.check(min(got, 0), "rtgs_launch_order")
+        assert got == n
+    return out
 
 
 class HipBackend:

@@ -120,3 +120,32 @@ def test_tile_deal_covers_every_tile_once():
             counts = [local_tile_count(total, r, world) for r in range(world)]
             assert counts == [lib.rtgs_num_local_tiles(w, h, r, world) for r in range(world)]
             assert sum(counts) == total and max(counts) - min(counts) <= 1
+
+
+def test_launch_orders_are_permutations_and_give_every_xcd_one_wedge():
+    """Launch orders only reschedule workgroups: each must name every local tile exactly once, for
+    whole frames and shards; in the wedge order the tiles at positions 8 i + x (workgroups the
+    round-robin dispatch hands to XCD x) must come from one angular sector of the image."""
+    import numpy as np
+    from rtgs import _native as nat
+    from rtgs.parallel import cost_sorted_order, local_tile_count, tiles_of
+    T = nat.tile_size()
+    for (w, h) in [(1920, 1080), (3840, 2160), (800, 600), (33, 1), (160, 160)]:
+        total = tiles_of(w, h, T)
+        for world in (1, 2, 8):
+            for rank in {0, world - 1}:
+                n = local_tile_count(total, rank, world)
+                for mode in ("centre", "wedge"):
+                    o = cost_sorted_order(w, h, T, rank, world, mode)
+                    assert o.dtype == np.int32 and sorted(o.tolist()) == list(range(n)), (w, h, world, rank, mode)
+    w, h = 1920, 1080
+    o = cost_sorted_order(w, h, T, 0, 1, "wedge")
+    tx = (w + T - 1) // T
+    ang = np.arctan2((o // tx + 0.5) * T - h / 2, (o % tx + 0.5) * T - w / 2)
+    n8 = len(o) // 8 * 8
+    spans = sorted((ang[x:n8:8].min(), ang[x:n8:8].max()) for x in range(8))
+    for (lo0, hi0), (lo1, hi1) in zip(spans, spans[1:]):
+        assert hi0 <= lo1                                   # sectors do not overlap
+    # most central first inside a wedge
+    m = np.maximum(np.abs((o % tx + 0.5) * T - w / 2) / (w / 2), np.abs((o // tx + 0.5) * T - h / 2) / (h / 2))
+    assert np.all(np.diff(m[0:n8:8]) >= 0)
