@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RTGS_ABI_VERSION 3
+#define RTGS_ABI_VERSION 4
 #define RTGS_MAX_DEPTH 16        /* peels kept per ray in one pass (__main__.py:70 default) */
 #ifndef RTGS_TILE
 #define RTGS_TILE 16             /* macro-tile edge in pixels: one workgroup, the unit of sharding */
@@ -174,6 +174,13 @@ int rtgs_trace(const RtgsScene* scene, const RtgsCamera* cam, const RtgsTracePar
  * quadratic of gaussian.py:215-219, factored per Gaussian instead of per ray). */
 int rtgs_project(const RtgsScene* scene, const RtgsCamera* cam, void* workspace,
                  size_t workspace_bytes, rtgs_stream_t stream);
+
+/* rtgs_project exactly as rtgs_trace(projected = 0) would run it for the shard (tile_first,
+ * tile_step): the supertile bins are only built when the shard is large enough for them to pay.
+ * For callers that overlap frame f+1's projection (on a second stream, into a second workspace)
+ * with frame f's trace, as rtgs.parallel.HipBackend.render does. */
+int rtgs_project_shard(const RtgsScene* scene, const RtgsCamera* cam, int32_t tile_first,
+                       int32_t tile_step, void* workspace, size_t workspace_bytes, rtgs_stream_t stream);
 
 /* One-call form of a whole sample (SURVEY.md 8(b) signature): rtgs_project + rtgs_trace of the
  * macro-tile ROWS [tile_y0, tile_y1) (rows of rtgs_tile_size() pixels in j; all rows = 0 ..

@@ -1728,6 +1728,20 @@ extern "C" int rtgs_project(const RtgsScene* scene, const RtgsCamera* cam, void*
   return project_impl(scene, cam, workspace, workspace_bytes, stream, true);
 }
 
+// k_bin is one more launch in front of the trace (7 us at c3, 20 us at c5): it pays while the
+// launch covers at least a sixth of the frame's tiles (c3: 1/4 shard 59.7 -> 54.8 us, 1/8 42.4 -> 40.0)
+static bool shard_wants_bins(const RtgsCamera* cam, int32_t local_tiles) {
+  return (int64_t)local_tiles * 6 >= rtgs_num_tiles(cam->width, cam->height);
+}
+
+extern "C" int rtgs_project_shard(const RtgsScene* scene, const RtgsCamera* cam, int32_t tile_first,
+                                  int32_t tile_step, void* workspace, size_t workspace_bytes,
+                                  rtgs_stream_t stream) {
+  if (!cam || tile_step <= 0 || tile_first < 0) return RTGS_EINVAL;
+  const int32_t local = rtgs_num_local_tiles(cam->width, cam->height, tile_first, tile_step);
+  return project_impl(scene, cam, workspace, workspace_bytes, stream, shard_wants_bins(cam, local));
+}
+
 // tile_limit caps the number of (tile_first, tile_step) tiles the launch covers (rtgs_render's
 // row ranges); rtgs_trace passes "all of them".
 static int trace_impl(const RtgsScene* scene, const RtgsCamera* cam, const RtgsTraceParams* params,
@@ -1744,10 +1758,7 @@ static int trace_impl(const RtgsScene* scene, const RtgsCamera* cam, const RtgsT
   if (local > tile_limit) local = tile_limit;
   if (local <= 0) return RTGS_OK;  // a shard with no tiles
   if (!projected) {
-    // k_bin is one more launch in front of the trace (3.5 us at c3, 20 us at c5): it pays while this
-    // launch covers at least a sixth of the frame's tiles (c3: 1/4 shard 59.7 -> 54.8 us, 1/8 42.4 -> 40.0)
-    const bool want_bins = (int64_t)local * 6 >= rtgs_num_tiles(cam->width, cam->height);
-    if (int rc = project_impl(scene, cam, workspace, workspace_bytes, stream, want_bins)) return rc;
+    if (int rc = project_impl(scene, cam, workspace, workspace_bytes, stream, shard_wants_bins(cam, local))) return rc;
   }
 
   const size_t nn = ((size_t)scene->n + 63) & ~(size_t)63;

@@ -14,7 +14,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_size_t, c_u
 
 import torch  # noqa: F401  (must precede the CDLL load, see module docstring)
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_DEPTH = 16
 RAY_FLOATS = 8
 SH_COEFFS = 15
@@ -62,6 +62,8 @@ PROTOTYPES = {
                              c_void_p]),
     "rtgs_project": (c_int32, [POINTER(RtgsScene), POINTER(RtgsCamera), c_void_p, c_size_t,
                                c_void_p]),
+    "rtgs_project_shard": (c_int32, [POINTER(RtgsScene), POINTER(RtgsCamera), c_int32, c_int32, c_void_p,
+                                     c_size_t, c_void_p]),
     "rtgs_untile": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "rtgs_closest_hit": (c_int32, [POINTER(RtgsScene), c_int32, c_void_p, c_void_p, c_void_p,
                                    c_void_p]),

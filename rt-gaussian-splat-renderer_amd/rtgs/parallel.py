@@ -82,6 +82,12 @@ class HipBackend:
         # 58.1 us per frame; direct launches cost the host 13.5 us and overlap the GPU)
         self.use_graph = os.environ.get("RTGS_GRAPH", "0") == "1"
         self._graphs = {}
+        # Optional (RTGS_PIPELINE=1): frame f+1's projection on a second stream, into a second
+        # workspace, while frame f is still being traced.  OFF by default: measured on MI355X / ROCm
+        # 7.2 the two cross-stream event waits per frame cost more than the overlap returns (c3
+        # 0.1553 -> 0.1618 ms per frame, c5 1.345 -> 1.382 with the host queueing 200 frames ahead)
+        self.pipeline = os.environ.get("RTGS_PIPELINE", "0") == "1"
+        self._pipe = None
 
     def tile_order(self, tile_first: int, tile_step: int):
         key = (tile_first, tile_step)
@@ -101,10 +107,11 @@ class HipBackend:
                                          nat.stream()), "rtgs_project")
 
     def trace(self, out, tile_first: int, tile_step: int, compact: bool, projected: bool = False,
-              split=None):
+              split=None, workspace=None):
         """split: None = the library picks the kernel form by launch size; True / False force the
         two-waves-per-tile / one-wave-per-tile form (same pixels either way)."""
         nat = self.nat
+        ws = self.workspace if workspace is None else workspace
         order = self.tile_order(tile_first, tile_step) if self.use_tile_order else None
         flags = nat.TRACE_COMPACT if compact else 0
         if split is not None:
@@ -112,8 +119,8 @@ class HipBackend:
         params = nat.RtgsTraceParams(self.depth, self.t_cutoff, tile_first, tile_step, flags,
                                      nat.ptr(order))
         nat.check(nat.lib().rtgs_trace(self.scene.native(), self.camera.native(), params,
-                                       nat.ptr(out), None, None, 1, nat.ptr(self.workspace),
-                                       self.workspace.numel(), 1 if projected else 0, nat.stream()),
+                                       nat.ptr(out), None, None, 1, nat.ptr(ws), ws.numel(),
+                                       1 if projected else 0, nat.stream()),
                   "rtgs_trace")
 
     # ---- hipGraph path ---------------------------------------------------------------------
@@ -133,8 +140,42 @@ class HipBackend:
         direct launches when graphs are disabled (RTGS_GRAPH=0)."""
         if self.use_graph:
             self.frame_graph(out, tile_first, tile_step, compact).replay()
+        elif self.pipeline:
+            self._render_pipelined(out, tile_first, tile_step, compact)
         else:
             self.trace(out, tile_first, tile_step, compact)
+
+    def _render_pipelined(self, out, tile_first: int, tile_step: int, compact: bool):
+        """project on a side stream into workspace f & 1, trace on the caller's stream once that
+        projection is done.  A frame's own latency is what it was (its trace waits for its
+        projection); a host that queues frames ahead of the GPU -- a turntable, bench.py, the
+        tile-parallel loop -- gets frame f+1's k_project / k_bin executed in the shadow of frame f's
+        k_trace, whose last workgroups leave most of the chip idle.  The pose and the scene pointers
+        are read when the frame is queued, as without the pipeline."""
+        nat = self.nat
+        if self._pipe is None:
+            self._pipe = dict(stream=torch.cuda.Stream(device=self.device), turn=0,
+                              ws=[self.workspace, torch.empty_like(self.workspace)],
+                              projected=[torch.cuda.Event(), torch.cuda.Event()],
+                              traced=[torch.cuda.Event(), torch.cuda.Event()])
+        pp = self._pipe
+        k = pp["turn"] & 1
+        pp["turn"] += 1
+        main = torch.cuda.current_stream(self.device)
+        side = pp["stream"]
+        ws = pp["ws"][k]
+        side.wait_event(pp["traced"][k])       # the trace two frames back was the last reader of ws
+        if pp.get("scene_version") != self.scene.version:
+            side.wait_stream(main)             # scene uploads / edits queued on the caller's stream
+            pp["scene_version"] = self.scene.version
+        with torch.cuda.stream(side):
+            nat.check(nat.lib().rtgs_project_shard(self.scene.native(), self.camera.native(), tile_first,
+                                                   tile_step, nat.ptr(ws), ws.numel(), nat.stream()),
+                      "rtgs_project_shard")
+            pp["projected"][k].record(side)
+        main.wait_event(pp["projected"][k])
+        self.trace(out, tile_first, tile_step, compact, projected=True, workspace=ws)
+        pp["traced"][k].record(main)
 
     def untile(self, gathered, world: int, tiles_per_rank: int, image):
         nat = self.nat

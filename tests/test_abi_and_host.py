@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
 def test_pure_host_entry_points():
     from rtgs import _native as nat
     lib = nat.lib()
-    assert lib.rtgs_abi_version() == nat.ABI_VERSION == 3
+    assert lib.rtgs_abi_version() == nat.ABI_VERSION == 4
     assert lib.rtgs_strerror(0) == b"ok"
     for code in (-1, -2, -3, -4, -5, -99):
         assert len(lib.rtgs_strerror(code)) > 0

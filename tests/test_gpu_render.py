@@ -674,6 +674,39 @@ def test_frame_graph_replays_with_new_poses():
         b.render(whole, 0, 1, compact=False)
 
 
+def test_pipelined_projection_equals_direct_launches():
+    # opt-in (RTGS_PIPELINE=1): frame f+1's rtgs_project_shard on a second stream and workspace while
+    # frame f is traced; frames queued back to back with a moving camera, checked only afterwards
+    from rtgs.parallel import HipBackend
+    from rtgs.utils.types import vec3, vec4
+    arrays, cam, depth = U.case("sh")
+    scene, camera, tracer = U.build(arrays, cam)
+    b = HipBackend(scene, camera, depth)
+    b.pipeline = True
+    w, h = cam["width"], cam["height"]
+    T = nat.tile_size()
+    per = (nat.lib().rtgs_num_tiles(w, h) + 2) // 3
+    poses = [(cam["position"], cam["rotation"]), ((0.9, -0.2, 2.4), scenes.quat_axis_angle((0.1, 1.0, 0.0), -0.3)),
+             ((-0.4, 0.3, 3.3), scenes.quat_axis_angle((1.0, 0.2, 0.1), 0.2)), (cam["position"], cam["rotation"]),
+             ((0.2, 0.1, 2.8), scenes.quat_axis_angle((0.0, 0.0, 1.0), 0.4))]
+    wholes = [b.alloc(w, h, 3) for _ in poses]
+    shards = [b.alloc(per, T, T, 3) for _ in poses]
+    for (pos, rot), whole, shard in zip(poses, wholes, shards):
+        camera.position, camera.rotation = vec3(pos), vec4(rot)
+        b.render(whole, 0, 1, compact=False)
+        b.render(shard, 1, 3, compact=True)
+    torch.cuda.synchronize()
+    assert b._pipe["turn"] == 2 * len(poses)
+    for (pos, rot), whole, shard in zip(poses, wholes, shards):
+        camera.position, camera.rotation = vec3(pos), vec4(rot)
+        tracer.trace(depth)
+        want_shard = torch.zeros_like(shard)
+        tracer.trace(depth, flags=nat.TRACE_COMPACT, tile_first=1, tile_step=3, sample_buf=want_shard)
+        torch.cuda.synchronize()
+        assert torch.equal(whole, tracer.sample_buf) and torch.equal(shard, want_shard)
+    assert float((wholes[0] - wholes[1]).abs().max()) > 1e-2
+
+
 def test_single_peel_calls_reuse_the_projection_and_track_scene_changes():
     # sample() x depth projects once (camera unchanged) yet must notice a new camera pose or a
     # re-committed scene
