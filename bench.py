@@ -215,31 +215,36 @@ def main():
         torch.cuda.synchronize()
         frame_ms_median = sorted(a_.elapsed_time(b_) for a_, b_ in evs)[len(evs) // 2]
 
-    # N > 1: two consecutive frames with DIFFERENT camera poses go through the double-buffered
-    # pipeline and must equal single-rank renders of the same poses bit for bit (a stale or
-    # swapped half of the double buffer would show here)
+    # N > 1: consecutive frames with DIFFERENT camera poses are queued back to back through the
+    # double-buffered pipeline (no host synchronisation in between); what is left in the
+    # framebuffer must equal the single-rank render of the LAST pose bit for bit -- for both
+    # orders of the two poses and for an odd number of frames, so that each half of the double
+    # buffer ends a sequence (a stale or swapped half would show the other pose)
     verified = None
     if world > 1:
-        poses = [(0.15, -0.1, 3.0), tuple(cam["position"])]
-        frames = []
-        for k, p in enumerate(poses):
-            camera.position = vec3(p)
-            renderer.render_frame()
-            if k > 0 and rank == 0:
-                torch.cuda.synchronize()
-                frames.append(renderer.framebuffer.clone())       # frame k-1 has just been completed
-        renderer.finish()
-        torch.cuda.synchronize()
+        pose_a, pose_b = (0.15, -0.1, 3.0), tuple(cam["position"])
+        sequences = [(pose_a, pose_b), (pose_b, pose_a), (pose_b, pose_a, pose_b)]
+        finals = []
+        for seq in sequences:
+            for p in seq:
+                camera.position = vec3(p)
+                renderer.render_frame()
+            renderer.finish()
+            torch.cuda.synchronize()
+            if rank == 0:
+                finals.append(renderer.framebuffer.clone())
         if rank == 0:
-            frames.append(renderer.framebuffer.clone())
             single = TileParallelRenderer(scene, camera, depth=cfg.depth, rank=0, world=1)
-            verified = True
-            for p, got in zip(poses, frames):
+            want = {}
+            for p in (pose_a, pose_b):
                 camera.position = vec3(p)
                 single.render_frame()
                 single.finish()
                 torch.cuda.synchronize()
-                verified = verified and bool(torch.equal(single.framebuffer, got))
+                want[p] = single.framebuffer.clone()
+            verified = not torch.equal(want[pose_a], want[pose_b])
+            for seq, got in zip(sequences, finals):
+                verified = verified and bool(torch.equal(want[seq[-1]], got))
         camera.position = vec3(cam["position"])
 
     if rank == 0:

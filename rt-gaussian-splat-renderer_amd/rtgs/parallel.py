@@ -107,11 +107,14 @@ class HipBackend:
                                          nat.stream()), "rtgs_project")
 
     def trace(self, out, tile_first: int, tile_step: int, compact: bool, projected: bool = False,
-              split=None, workspace=None):
+              split=None, workspace=None, stream=None):
         """split: None = the library picks the kernel form by launch size; True / False force the
-        two-waves-per-tile / one-wave-per-tile form (same pixels either way)."""
+        two-waves-per-tile / one-wave-per-tile form (same pixels either way).  stream: a
+        torch.cuda.Stream to launch on instead of the current one (the C ABI takes the stream as
+        an argument: no need to make it current)."""
         nat = self.nat
         ws = self.workspace if workspace is None else workspace
+        st = nat.stream() if stream is None else stream.cuda_stream
         order = self.tile_order(tile_first, tile_step) if self.use_tile_order else None
         flags = nat.TRACE_COMPACT if compact else 0
         if split is not None:
@@ -120,7 +123,7 @@ class HipBackend:
                                      nat.ptr(order))
         nat.check(nat.lib().rtgs_trace(self.scene.native(), self.camera.native(), params,
                                        nat.ptr(out), None, None, 1, nat.ptr(ws), ws.numel(),
-                                       1 if projected else 0, nat.stream()),
+                                       1 if projected else 0, st),
                   "rtgs_trace")
 
     # ---- hipGraph path ---------------------------------------------------------------------
@@ -135,15 +138,15 @@ class HipBackend:
             self._graphs[key] = g
         return g
 
-    def render(self, out, tile_first: int, tile_step: int, compact: bool):
-        """project + trace of one shard into `out` on the current stream: graph replay, or two
-        direct launches when graphs are disabled (RTGS_GRAPH=0)."""
-        if self.use_graph:
+    def render(self, out, tile_first: int, tile_step: int, compact: bool, stream=None):
+        """project + trace of one shard into `out`: two direct launches on `stream` (default: the
+        current stream), or -- opt-in, current stream only -- a graph replay / the pipelined form."""
+        if stream is None and self.use_graph:
             self.frame_graph(out, tile_first, tile_step, compact).replay()
-        elif self.pipeline:
+        elif stream is None and self.pipeline:
             self._render_pipelined(out, tile_first, tile_step, compact)
         else:
-            self.trace(out, tile_first, tile_step, compact)
+            self.trace(out, tile_first, tile_step, compact, stream=stream)
 
     def _render_pipelined(self, out, tile_first: int, tile_step: int, compact: bool):
         """project on a side stream into workspace f & 1, trace on the caller's stream once that
@@ -245,25 +248,59 @@ class TileParallelRenderer:
         self.framebuffer = b.alloc(b.width, b.height, 3) if (self.world == 1 or self.rank == self.dst) else None
         self._pending = None
         self._frame = 0
+        self._comm = None
         if self.world > 1:
             shard = (self.tiles_per_rank, self.TILE, self.TILE, 3)
             self.compact = [b.alloc(*shard), b.alloc(*shard)]
             self.gathered = ([b.alloc(self.world, *shard), b.alloc(self.world, *shard)]
                              if self.rank == self.dst else [None, None])
+            # the per-rank views torch.distributed.gather wants, made once (8 views cost ~8 us per frame)
+            self._glist = [list(g.unbind(0)) if g is not None else None for g in self.gathered]
+            if isinstance(b, HipBackend) and os.environ.get("RTGS_RENDER_STREAM", "1") != "0":
+                # Two streams: the shard is rendered on a stream of its own (handed to the C ABI as
+                # an argument, never made current), the gather and the untile stay on the caller's
+                # stream.  Neither waits for the other's current frame -- only for the buffer it is
+                # about to reuse -- and the collective can be issued in its blocking form, which
+                # costs the host 16 us instead of the 28 us of async_op=True + wait()
+                # (tools/host_overhead.py)
+                self._comm = dict(render=torch.cuda.Stream(device=b.device),
+                                  traced=[torch.cuda.Event(), torch.cuda.Event()],
+                                  sent=[torch.cuda.Event(), torch.cuda.Event()])
 
     # ---- frame loop ------------------------------------------------------------------------
     def render_frame(self) -> None:
         """Queue one frame.  world == 1: straight into ``framebuffer``.  world > 1: trace this
-        rank's tiles, start the gather, then complete the previous frame (double buffering)."""
+        rank's tiles into one of two compact buffers on the render stream, gather them (and, on
+        rank dst, untile) on the caller's stream while the render stream goes on with the next
+        frame: ``framebuffer`` is complete in the caller's stream order.  (Without a HIP backend
+        -- the CPU tests' stand-in -- or with RTGS_RENDER_STREAM=0: one stream; start the gather,
+        then complete the previous frame.)"""
         b = self.backend
         if self.world == 1:
             b.render(self.framebuffer, 0, 1, compact=False)
             return
         k = self._frame & 1
         self._frame += 1
+        glist = self._glist[k]
+        if self._comm is not None:
+            cm = self._comm
+            rs = cm["render"]
+            if cm.get("scene_version") != b.scene.version:
+                rs.wait_stream(torch.cuda.current_stream(b.device))   # scene uploads / edits queued there
+                cm["scene_version"] = b.scene.version
+            rs.wait_event(cm["sent"][k])           # the gather two frames back has read compact[k]
+            if self.local_tiles:
+                b.render(self.compact[k], self.rank, self.world, compact=True, stream=rs)
+            cm["traced"][k].record(rs)
+            cm["traced"][k].wait()                 # the caller's stream: gather this frame's shard
+            self._gather(self.compact[k], gather_list=glist, dst=self.dst, group=self.group,
+                         async_op=False)
+            cm["sent"][k].record()
+            if self.rank == self.dst:
+                b.untile(self.gathered[k], self.world, self.tiles_per_rank, self.framebuffer)
+            return
         if self.local_tiles:
             b.render(self.compact[k], self.rank, self.world, compact=True)
-        glist = list(self.gathered[k].unbind(0)) if self.rank == self.dst else None
         work = self._gather(self.compact[k], gather_list=glist, dst=self.dst, group=self.group,
                             async_op=True)
         prev, self._pending = self._pending, (work, k)

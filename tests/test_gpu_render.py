@@ -607,6 +607,7 @@ class _FakeComm:
         self.sent = {}
 
     def gather(self, tensor, gather_list=None, dst=0, group=None, async_op=False):
+        torch.cuda.synchronize()      # the emulated ranks' streams know nothing of each other
         if self.rank != dst:
             self.sent[self.rank] = tensor.clone()
         else:

@@ -38,5 +38,28 @@ print("untile:                          host %.1f us, total %.1f us" % timeit(la
 def gat():
     w = dist.gather(compact, gather_list=[gathered[0]], dst=0, async_op=True); w.wait()
 print("dist.gather world=1 (+wait):     host %.1f us, total %.1f us" % timeit(gat))
+def agt():
+    w = dist.all_gather_into_tensor(gathered, compact, async_op=True); w.wait()
+print("all_gather_into_tensor world=1:  host %.1f us, total %.1f us" % timeit(agt))
+def agt_sync():
+    dist.all_gather_into_tensor(gathered, compact)
+print("  same, async_op=False:          host %.1f us, total %.1f us" % timeit(agt_sync))
+def gat_sync():
+    dist.gather(compact, gather_list=[gathered[0]], dst=0)
+print("dist.gather world=1 sync:        host %.1f us, total %.1f us" % timeit(gat_sync))
 print("full frame world=1:              host %.1f us, total %.1f us" % timeit(lambda: r.render_frame()))
+# rank 0 of 8, the real frame loop, with a gather that makes the real RCCL call for one peer's worth
+# (world-1 process group): host cost and stream structure are the production ones, the 7 transfers are not
+def gather1(tensor, gather_list=None, dst=0, group=None, async_op=False):
+    return dist.gather(tensor, gather_list=[gather_list[0]], dst=0, async_op=async_op)
+for mode in ("1", "0"):
+    os.environ["RTGS_RENDER_STREAM"] = mode
+    r8 = TileParallelRenderer(scene, camera, depth=16, rank=0, world=8, gather_fn=gather1)
+    res = timeit(lambda: r8.render_frame())
+    r8.finish()
+    print("rank 0 of 8 frame loop, RTGS_RENDER_STREAM=%s: host %.1f us, total %.1f us" % ((mode,) + res))
+ev = torch.cuda.Event(); side = torch.cuda.Stream()
+print("event.record(stream):            host %.1f us, total %.1f us" % timeit(lambda: ev.record(side)))
+print("event.wait():                    host %.1f us, total %.1f us" % timeit(lambda: ev.wait()))
+print("stream.wait_event(event):        host %.1f us, total %.1f us" % timeit(lambda: side.wait_event(ev)))
 dist.destroy_process_group()
