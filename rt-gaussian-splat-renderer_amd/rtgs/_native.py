@@ -144,9 +144,27 @@ def ptr(t) -> int | None:
     return None if t is None else t.data_ptr()
 
 
+# torch.cuda.current_stream() costs ~8 us per call (device-index parsing, availability checks):
+# three of them per frame were a third of the tile-parallel loop's host time.  The two private
+# accessors below are what it ends in; fall back to the public path where they are missing.
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_stream = getattr(torch._C, "_cuda_getCurrentStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream() -> int:
     """The hipStream_t of torch's current stream, as the void* the ABI takes."""
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
+
+
+def current_stream(device_index: int) -> "torch.cuda.Stream":
+    """torch.cuda.current_stream(device_index) without its argument handling."""
+    if _cur_stream is not None:
+        sid, didx, dtype = _cur_stream(device_index)
+        return torch.cuda.Stream(stream_id=sid, device_index=didx, device_type=dtype)
+    return torch.cuda.current_stream(device_index)
 
 
 def device() -> torch.device:

@@ -180,10 +180,11 @@ class HipBackend:
         self.trace(out, tile_first, tile_step, compact, projected=True, workspace=ws)
         pp["traced"][k].record(main)
 
-    def untile(self, gathered, world: int, tiles_per_rank: int, image):
+    def untile(self, gathered, world: int, tiles_per_rank: int, image, stream=None):
         nat = self.nat
+        st = nat.stream() if stream is None else stream.cuda_stream
         nat.check(nat.lib().rtgs_untile(nat.ptr(gathered), world, tiles_per_rank, self.width,
-                                        self.height, nat.ptr(image), nat.stream()), "rtgs_untile")
+                                        self.height, nat.ptr(image), st), "rtgs_untile")
 
 
 class _FrameGraph:
@@ -285,19 +286,25 @@ class TileParallelRenderer:
         if self._comm is not None:
             cm = self._comm
             rs = cm["render"]
+            cur = b.nat.current_stream(b.device.index)    # the caller's stream
             if cm.get("scene_version") != b.scene.version:
-                rs.wait_stream(torch.cuda.current_stream(b.device))   # scene uploads / edits queued there
+                rs.wait_stream(cur)                # scene uploads / edits queued there
                 cm["scene_version"] = b.scene.version
-            rs.wait_event(cm["sent"][k])           # the gather two frames back has read compact[k]
+            # the gather two frames back has read compact[k].  (Guarding the reuse from the host
+            # instead -- event.synchronize() on a ring of 2 or 4 buffers -- keeps this barrier packet
+            # off the render stream but blocks a host that runs ahead, every frame: 79 / 73 us per
+            # frame against 67.)
+            rs.wait_event(cm["sent"][k])
             if self.local_tiles:
                 b.render(self.compact[k], self.rank, self.world, compact=True, stream=rs)
             cm["traced"][k].record(rs)
-            cm["traced"][k].wait()                 # the caller's stream: gather this frame's shard
+            cur.wait_event(cm["traced"][k])        # gather this frame's shard once it is traced
             self._gather(self.compact[k], gather_list=glist, dst=self.dst, group=self.group,
                          async_op=False)
-            cm["sent"][k].record()
+            cm["sent"][k].record(cur)
             if self.rank == self.dst:
-                b.untile(self.gathered[k], self.world, self.tiles_per_rank, self.framebuffer)
+                b.untile(self.gathered[k], self.world, self.tiles_per_rank, self.framebuffer,
+                         stream=cur)
             return
         if self.local_tiles:
             b.render(self.compact[k], self.rank, self.world, compact=True)
