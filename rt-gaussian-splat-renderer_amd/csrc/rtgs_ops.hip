@@ -156,6 +156,7 @@ struct AccelView {
   const double* minv;      // [nn][6]
   const float* slab_box;   // [nslabs][8]
   const float* group_box;  // [ngroups][8]
+  const float* rad2;       // [nn] squared radius of the ball about the centre that holds the ellipsoid
   int32_t nslabs, ngroups;
 };
 
@@ -164,7 +165,8 @@ __host__ __device__ inline size_t accel_nn(int32_t n) { return ((size_t)n + 63) 
 __global__ __launch_bounds__(256) void k_accel_build(int32_t n, const float* __restrict__ pos,
                                                       const float* __restrict__ rot,
                                                       const float* __restrict__ scale,
-                                                      double* __restrict__ minv, float* __restrict__ slab_box) {
+                                                      double* __restrict__ minv, float* __restrict__ slab_box,
+                                                      float* __restrict__ rad2) {
   const int g0 = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = g0 < n;
   const int g = live ? g0 : n - 1;
@@ -180,6 +182,10 @@ __global__ __launch_bounds__(256) void k_accel_build(int32_t n, const float* __r
     quat_to_mat3(q, R);
     const double s2[3] = {(double)scale[3 * g] * scale[3 * g], (double)scale[3 * g + 1] * scale[3 * g + 1],
                           (double)scale[3 * g + 2] * scale[3 * g + 2]};
+    // {m : m^T Sigma^-1 m <= 3} has semi-axes sqrt(3) |q|^2 |s_k| (R is |q|^2 x a rotation): it lies
+    // in the ball of that radius for the largest |s_k|.  Rounded up; NaN stays NaN (never rejects).
+    const double k2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    rad2[g] = __double2float_ru(3.0 * k2 * k2 * fmax(s2[0], fmax(s2[1], s2[2])) * (1.0 + 1e-6));
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const double sii = R[3 * i] * R[3 * i] * s2[0] + R[3 * i + 1] * R[3 * i + 1] * s2[1] + R[3 * i + 2] * R[3 * i + 2] * s2[2];
@@ -221,8 +227,9 @@ __global__ __launch_bounds__(256) void k_accel_groups(int32_t nslabs, const floa
 // Can the ray (o + t d, fp32 as stored) have a point inside the box for some t in [t_lo, t_hi]?
 // Conservative: the slab distances are padded by 1e-6 relative.  A zero direction component
 // constrains nothing if the origin lies between the two planes, everything otherwise.
+// tn_out: the (padded) parameter at which the ray enters the box.
 __device__ __forceinline__ bool box_may_hit(const float* __restrict__ b, const float o[3], const float d[3],
-                                            const float inv[3], float t_lo, float t_hi) {
+                                            const float inv[3], float t_lo, float t_hi, float* tn_out = nullptr) {
   float tn = -kInf, tf = kInf;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -238,7 +245,15 @@ __device__ __forceinline__ bool box_may_hit(const float* __restrict__ b, const f
   }
   tn -= fabsf(tn) * 1e-6f;
   tf += fabsf(tf) * 1e-6f;
+  if (tn_out) *tn_out = tn;
   return tn <= tf && tf >= t_lo && tn <= t_hi;
+}
+
+// wave-wide minimum of an unsigned value (xor butterfly)
+__device__ __forceinline__ unsigned wave_umin_u32(unsigned v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, off));
+  return v;
 }
 
 __device__ __forceinline__ Closest closest_hit_accel(const AccelView av, int32_t n, const float* __restrict__ pos,
@@ -249,26 +264,83 @@ __device__ __forceinline__ Closest closest_hit_accel(const AccelView av, int32_t
   const float fo[3] = {(float)o[0], (float)o[1], (float)o[2]};   // exact: rays are stored in fp32
   const float fd[3] = {(float)d[0], (float)d[1], (float)d[2]};
   const float inv[3] = {1.0f / fd[0], 1.0f / fd[1], 1.0f / fd[2]};
+  const int lane = threadIdx.x & (kWave - 1);
+  const double dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
   float t_hi = end;   // min(end, best t1 so far), rounded up
-  for (int u = 0; u < av.ngroups; ++u) {
-    const bool hu = live && box_may_hit(av.group_box + (size_t)u * kBoxFloats, fo, fd, inv, start, t_hi);
-    if (!__any(hu)) continue;
-    const int s_end = min(av.nslabs, (u + 1) * kAccGroup);
-    for (int sl = u * kAccGroup; sl < s_end; ++sl) {
-      const bool hs = hu && box_may_hit(av.slab_box + (size_t)sl * kBoxFloats, fo, fd, inv, start, t_hi);
-      if (!__any(hs)) continue;
-      const int g_end = min(n, (sl + 1) * kWave);
-      for (int g = sl * kWave; g < g_end; ++g) {
-        if (hs) {
-          const HitD h = hit_quadratic(o, d, pos + 3 * (size_t)g, av.minv + 6 * (size_t)g);
-          const float t1f = (float)h.t1;   // the window is tested in fp32: see closest_hit_block
-          if (t1f < end && t1f > start && h.t1 < c.t1) {
-            c.t1 = h.t1; c.t2 = h.t2; c.idx = g;
-            t_hi = fminf(t_hi, __double2float_ru(h.t1));
+  // Groups are visited NEAREST FIRST within each run of 64 (by the smallest distance at which any
+  // ray of the wave enters the group's box), so that the first hits shrink every ray's window
+  // before the far groups are looked at; index order made a ray walk every box along its whole
+  // length.  The answer does not depend on the order: the closest hit is the minimum of (t1, index).
+  // (The 16 slabs of a group nearest first as well: c3 1.24 -> 1.17 ms, c5 5.30 -> 5.40: not kept.)
+  constexpr unsigned kSkip = 0xFFFFFFFFu;
+  auto group_key = [&](int u) -> unsigned {
+    float tn;
+    const bool hu = live && box_may_hit(av.group_box + (size_t)u * kBoxFloats, fo, fd, inv, start, t_hi, &tn);
+    // entry distances below `start` order alike; non-negative floats order like their bits
+    return hu ? __float_as_uint(fmaxf(fmaxf(tn, start), 0.f)) : kSkip;
+  };
+  auto visit_run = [&](int base) {
+    const int cnt = min(kWave, av.ngroups - base);
+    unsigned mykey = kSkip;   // lane j: key of group base + j
+    for (int j = 0; j < cnt; ++j) {
+      const unsigned kmin = wave_umin_u32(group_key(base + j));
+      if (lane == j) mykey = kmin;
+    }
+    while (true) {
+      const unsigned kmin = wave_umin_u32(mykey);
+      if (kmin == kSkip) break;
+      const int j = __builtin_ctzll(__ballot(mykey == kmin));
+      if (lane == j) mykey = kSkip;
+      const int u = base + j;
+      const bool hu = live && box_may_hit(av.group_box + (size_t)u * kBoxFloats, fo, fd, inv, start, t_hi);
+      if (!__any(hu)) continue;
+      const int s_end = min(av.nslabs, (u + 1) * kAccGroup);
+      for (int sl = u * kAccGroup; sl < s_end; ++sl) {
+        const bool hs = hu && box_may_hit(av.slab_box + (size_t)sl * kBoxFloats, fo, fd, inv, start, t_hi);
+        if (!__any(hs)) continue;
+        const int g_end = min(n, (sl + 1) * kWave);
+        for (int g = sl * kWave; g < g_end; ++g) {
+          if (hs) {
+            // the ray's line must pass through the Gaussian's bounding ball: |m x d|^2 <= r^2 |d|^2 with
+            // m = o - mu -- a dozen fp64 operations that spare most candidates of a slab the quadratic.
+            // Conservative (radius rounded up, slack for the cancellation); NaNs fall through.
+            const float* mu = pos + 3 * (size_t)g;
+            const double mx = o[0] - (double)mu[0], my = o[1] - (double)mu[1], mz = o[2] - (double)mu[2];
+            const double md = mx * d[0] + my * d[1] + mz * d[2], mm = mx * mx + my * my + mz * mz;
+            if (mm * dd - md * md > (double)av.rad2[g] * dd * (1.0 + 1e-6) + 1e-13 * mm * dd) continue;
+            const HitD h = hit_quadratic(o, d, mu, av.minv + 6 * (size_t)g);
+            const float t1f = (float)h.t1;   // the window is tested in fp32: see closest_hit_block
+            // (t1, index) lexicographic: what increasing-index order with a strict `<` gives
+            if (t1f < end && t1f > start && (h.t1 < c.t1 || (h.t1 == c.t1 && g < c.idx))) {
+              c.t1 = h.t1; c.t2 = h.t2; c.idx = g;
+              t_hi = fminf(t_hi, __double2float_ru(h.t1));
+            }
           }
         }
       }
     }
+  };
+  const int nruns = (av.ngroups + kWave - 1) / kWave;
+  if (nruns > 1 && nruns <= kWave) {
+    // the runs themselves nearest first (lane r keeps run r's key: up to 64 runs = 4 M Gaussians;
+    // beyond that the runs are taken in index order)
+    unsigned rkey = kSkip;
+    for (int r = 0; r < nruns; ++r) {
+      unsigned k = kSkip;
+      const int u_end = min(av.ngroups, (r + 1) * kWave);
+      for (int u = r * kWave; u < u_end; ++u) k = min(k, group_key(u));
+      k = wave_umin_u32(k);
+      if (lane == r) rkey = k;
+    }
+    while (true) {
+      const unsigned kmin = wave_umin_u32(rkey);
+      if (kmin == kSkip) break;
+      const int r = __builtin_ctzll(__ballot(rkey == kmin));
+      if (lane == r) rkey = kSkip;
+      visit_run(r * kWave);
+    }
+  } else {
+    for (int base = 0; base < av.ngroups; base += kWave) visit_run(base);
   }
   return c;
 }
@@ -522,11 +594,11 @@ int rtgs_generate_rays(const RtgsCamera* cam, float* rays, rtgs_stream_t stream)
 size_t rtgs_accel_bytes(int32_t n) {
   if (n <= 0) return 0;
   const size_t nn = accel_nn(n), nslabs = nn / kWave, ngroups = (nslabs + kAccGroup - 1) / kAccGroup;
-  return nn * 6 * sizeof(double) + (nslabs + ngroups) * kBoxFloats * sizeof(float);
+  return nn * 6 * sizeof(double) + (nslabs + ngroups) * kBoxFloats * sizeof(float) + nn * sizeof(float);
 }
 
 static int accel_view(const RtgsScene* scene, const void* accel, size_t accel_bytes, AccelView* av) {
-  *av = AccelView{nullptr, nullptr, nullptr, 0, 0};
+  *av = AccelView{nullptr, nullptr, nullptr, nullptr, 0, 0};
   if (!accel) return RTGS_OK;   // brute force
   if (accel_bytes < rtgs_accel_bytes(scene->n)) return RTGS_EWORKSPACE;
   if (reinterpret_cast<uintptr_t>(accel) & 15u) return RTGS_EINVAL;
@@ -536,6 +608,7 @@ static int accel_view(const RtgsScene* scene, const void* accel, size_t accel_by
   av->minv = static_cast<const double*>(accel);
   av->slab_box = reinterpret_cast<const float*>(av->minv + nn * 6);
   av->group_box = av->slab_box + (size_t)av->nslabs * kBoxFloats;
+  av->rad2 = av->group_box + (size_t)av->ngroups * kBoxFloats;
   return RTGS_OK;
 }
 
@@ -545,7 +618,8 @@ int rtgs_accel_build(const RtgsScene* scene, void* accel, size_t accel_bytes, rt
   if (int rc = accel_view(scene, accel, accel_bytes, &av)) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(k_accel_build, grid_for(scene->n, 256), dim3(256), 0, s, scene->n, scene->position,
-                     scene->rotation, scene->scale, const_cast<double*>(av.minv), const_cast<float*>(av.slab_box));
+                     scene->rotation, scene->scale, const_cast<double*>(av.minv), const_cast<float*>(av.slab_box),
+                     const_cast<float*>(av.rad2));
   hipLaunchKernelGGL(k_accel_groups, grid_for(av.ngroups, 256), dim3(256), 0, s, av.nslabs, av.slab_box,
                      const_cast<float*>(av.group_box));
   return check_launch();

@@ -297,6 +297,40 @@ def test_accelerated_scene_hit_equals_brute_force_bit_for_bit():
                                             nat.ptr(ia), nat.ptr(ta), nat.stream()) == -3
 
 
+def test_accelerated_scene_hit_orders_do_not_change_ties_or_answers():
+    # nearest-first traversal (runs of 64 groups, groups inside a run) and the bounding-ball reject:
+    # 80 k Gaussians = 79 groups = 2 runs, the last 3 000 exact copies of the first 3 000 -- every hit
+    # of a copied Gaussian is an exact t1 tie between two indices that sit in different runs (caller's
+    # order) or side by side (Morton order); brute force keeps the lower index, and so must this
+    from rtgs import synthetic
+    arrays = synthetic.make_scene(80_000, 1.5, 91)
+    for k in ("position", "rotation", "scale", "color", "opacity"):
+        arrays[k][-3000:] = arrays[k][:3000]
+    arrays["scale"][:3000] *= 2.0
+    arrays["scale"][-3000:] *= 2.0          # big enough to be hit often
+    rng = np.random.default_rng(5)
+    n = 8000
+    o = rng.uniform(-2.5, 2.5, (n, 3)).astype(np.float32)
+    tgt = arrays["position"][rng.integers(0, 3000, n)] + rng.normal(size=(n, 3)).astype(np.float32) * 0.01
+    d = (tgt - o).astype(np.float32)
+    d[n // 2:] = rng.normal(size=(n - n // 2, 3)).astype(np.float32)
+    rays = torch.from_numpy(np.concatenate([o, d, np.zeros((n, 1), np.float32), np.full((n, 1), np.inf, np.float32)], axis=1)).cuda()
+    ties = 0
+    for spatial in (False, True):
+        scene = rtgs.Scene()
+        scene.sort_spatially = spatial
+        scene.set_arrays(**arrays)
+        ia, ta = scene.hit_batch(rays)
+        ib, tb = scene.hit_batch(rays, brute_force=True)
+        torch.cuda.synchronize()
+        assert torch.equal(ia, ib) and torch.equal(ta, tb)
+        if not spatial:      # caller's order: indices are the caller's, a copied Gaussian must answer as its original
+            hit = ia[ia >= 0]
+            ties = int((hit < 3000).sum())
+            assert int((hit >= 77_000).sum()) == 0
+    assert ties > 500
+
+
 def test_scene_load_file():
     # reference tests/test_scene.py:16-23: loading tests/data/test.ply must not raise
     path = os.path.join(U.GOLDEN, "test.ply")
