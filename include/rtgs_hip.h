@@ -204,7 +204,8 @@ int rtgs_closest_hit(const RtgsScene* scene, int32_t n_rays, const float* rays,
 
 /* Acceleration structure for the two arbitrary-ray queries (what the reference's BVH is to its
  * Scene.hit, scene.py:162-450): per-Gaussian fp64 inverse covariances, exact world-space boxes of
- * every 64 consecutive Gaussians and of every 16 such slabs.  It helps when consecutive Gaussians
+ * every 64 consecutive Gaussians and of every 16 such slabs, the squared radius of each Gaussian's
+ * bounding ball.  Boxes are visited nearest first per wave of 64 rays.  It helps when consecutive Gaussians
  * are spatially close (rtgs.Scene stores them in Morton order); answers are identical to the
  * brute-force calls for any order.  Build once per scene (caller-owned buffer of
  * rtgs_accel_bytes(n) bytes, 16-B aligned), rebuild when the Gaussians change.
