@@ -294,7 +294,8 @@ class TileParallelRenderer:
             # instead -- event.synchronize() on a ring of 2 or 4 buffers -- keeps this barrier packet
             # off the render stream but blocks a host that runs ahead, every frame: 79 / 73 us per
             # frame against 67.)
-            rs.wait_event(cm["sent"][k])
+            if not cm["sent"][k].query():          # usually long done: then the render stream is spared the packet
+                rs.wait_event(cm["sent"][k])
             if self.local_tiles:
                 b.render(self.compact[k], self.rank, self.world, compact=True, stream=rs)
             cm["traced"][k].record(rs)
