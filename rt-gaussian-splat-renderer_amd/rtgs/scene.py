@@ -176,6 +176,10 @@ class Scene:
         self.num_gaussians = n
         self.version += 1
         dev = f.position.device
+        if self.position is not None:
+            # a re-commit frees the streamed copies: frames still in flight on another stream (the
+            # tile-parallel loop renders on its own) must have finished reading them
+            torch.cuda.synchronize(dev)
         if self.sort_spatially and n > 64:
             self.order = morton_order(f.position, f.scale)
         else:
