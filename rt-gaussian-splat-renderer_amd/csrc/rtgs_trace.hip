@@ -54,7 +54,9 @@ namespace {
 // pressure); IEEE division/sqrt +8 %; 32x32 macro-tiles 0.475, 8x8 single-wave workgroups 0.473;
 // a second slab level (1024-Gaussian groups) -12 % at 100 k Gaussians (it is what Tune<true> uses
 // above 262 k); XCD-contiguous tile chunks 0.444 (centre-heavy scene: imbalance), row-striped
-// XCD map no gain; software-pipelining insertion(k) with the test of k+1 0.329.
+// XCD map no gain (round 2: one equal-count image WEDGE per XCD, most central tile first inside
+// it, is a gain -- rtgs_launch_order below); software-pipelining insertion(k) with the test of
+// k+1 0.329.
 #ifndef RTGS_STAMPS
 #define RTGS_STAMPS 0     // diagnostic build: per-phase s_memtime stamps of wave 0 into the buffer
 #endif                    // passed as attenuation_buf (8 x u64 per block); never quote its run time
