@@ -49,6 +49,14 @@ def test_pure_host_entry_points():
     assert lib.rtgs_num_local_tiles(1920, 1080, 0, 1) == total
     assert lib.rtgs_num_local_tiles(t, t, 3, 8) == 0        # more ranks than tiles
     assert lib.rtgs_num_local_tiles(t, t, 0, 0) == 0
+    # rtgs_launch_order: host-only; bad arguments are refused, a one-tile image has one order
+    import numpy as np
+    one = np.full(4, -7, dtype=np.int32)
+    assert lib.rtgs_launch_order(t, t, 0, 1, 1, one.ctypes.data) == 1 and one.tolist() == [0, -7, -7, -7]
+    assert lib.rtgs_launch_order(1920, 1080, 0, 1, 1, None) == -1
+    assert lib.rtgs_launch_order(1920, 1080, 0, 1, 2, one.ctypes.data) == -1      # unknown kind
+    assert lib.rtgs_launch_order(1920, 1080, 0, 0, 1, one.ctypes.data) == -1      # no tiles
+    assert lib.rtgs_accel_bytes(0) == 0 and lib.rtgs_accel_bytes(100_000) >= 100_000 * 52
 
 
 def test_argument_validation_needs_no_gpu():
