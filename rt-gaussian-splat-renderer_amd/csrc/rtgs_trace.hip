@@ -1466,9 +1466,29 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
             // each -- with the weights T alpha handed over in the exponent slots: c3 + SH 0.289 ->
             // 0.317, c5 1.30 -> 1.99: one event's 45 coefficients at a time leaves the scalar-load
             // latency exposed, the log's LDS costs c5 a workgroup per CU, and 23 x 68 v_pk_fma_f32
-            // per wave is 1.6 x the arithmetic of 14 x 68.)
+            // per wave is 1.6 x the arithmetic of 14 x 68.  Coefficients read per lane from LDS
+            // instead (timing-only build RTGS_SH_ABLATE=3, nothing staged): c3 + SH 0.290 -> 0.200,
+            // c5 1.306 -> 1.122 -- the bound of staging a wave's distinct Gaussians in LDS; but the
+            // 192 B per staged Gaussian cost a workgroup per CU beyond ~20 per wave, and with one
+            // workgroup less the same builds run at 0.281 / 1.385: nothing left.)
             const float* sp = sh + (size_t)gi * (RTGS_SH_COEFFS * 3);
-#if RTGS_SH_ABLATE == 1   // timing only: the loads without the arithmetic
+#if RTGS_SH_ABLATE == 3   // timing only: the coefficients from LDS (whatever s_w holds) instead of memory
+            if constexpr (kLdsW) {
+              const float4* lp = reinterpret_cast<const float4*>(s_w) + (gi & 63u) * 12u;   // 48-float records
+              float cf[48];
+#pragma unroll
+              for (int j = 0; j < 12; ++j) {
+                const float4 v = lp[j];
+                cf[4 * j] = v.x; cf[4 * j + 1] = v.y; cf[4 * j + 2] = v.z; cf[4 * j + 3] = v.w;
+              }
+#pragma unroll
+              for (int q = 0; q < RTGS_SH_COEFFS; ++q) {
+                co.x += Ysh[q] * cf[3 * q + 0];
+                co.y += Ysh[q] * cf[3 * q + 1];
+                co.z += Ysh[q] * cf[3 * q + 2];
+              }
+            }
+#elif RTGS_SH_ABLATE == 1   // timing only: the loads without the arithmetic
 #pragma unroll
             for (int q = 0; q < RTGS_SH_COEFFS; ++q) {
               float v0 = sp[3 * q + 0], v1 = sp[3 * q + 1], v2 = sp[3 * q + 2];
