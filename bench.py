@@ -31,7 +31,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X spec peak, /opt/skills/guides/MI355X_MICROARCH.m
 # VALU issue peak: 256 CUs x 4 SIMDs, one wave64 VALU instruction per SIMD every 2 cycles
 # (SIMD-32: MI355X_MICROARCH.md "v_fma_f32 (wave64) 2 cyc"), at the 2.4 GHz peak engine clock.
 # (Inside k_trace the clock measures 2.14 GHz -- s_memtime against the 100 MHz s_memrealtime,
-# tools/stamps.py, profiles/r02_c3_phase_stamps.txt; the fraction below is against the 2.4 GHz peak.)
+# tools/stamps.py, profiles/r02_phase_stamps.txt; the fraction below is against the 2.4 GHz peak.)
 N_SIMD = 1024
 ENGINE_CLOCK_HZ = 2.4e9
 VALU_PEAK_GINST = N_SIMD * ENGINE_CLOCK_HZ / 2 / 1e9   # G wave-instructions / s
