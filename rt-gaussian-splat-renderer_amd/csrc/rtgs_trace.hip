@@ -1280,6 +1280,9 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
                 // mostly land in the upper half (c3: 0.1634 -> 0.1551 ms).  Four blocks of four with a
                 // ballot each lose again (0.211: too many small basic blocks), and three straight-line
                 // cases (short / both halves / upper only) make the register allocator spill 107 VGPRs.
+                // Fill stages of 4 / 8 / 12 / 16 slots instead of 8 / 16 (no extra ballots, same registers):
+                // c3 0.1357-0.1370 -> 0.1376-0.1386, c5 1.299 -> 1.355 -- the branches cost more than the
+                // 128 skipped instructions per wave.
                 const bool low = kTier == kK || tier_short || wave_any(kn < key[kTier - 1]);
                 if constexpr (kTier < kK) {
                   if (!tier_short) list_insert2<kTier, kK>(key, kidx, kn, pn);
