@@ -42,7 +42,7 @@ extern "C" {
 enum {
   RTGS_OK = 0,
   RTGS_EINVAL = -1,      /* NULL pointer, non-positive size, bad enum */
-  RTGS_EDEPTH = -2,      /* depth outside [1, RTGS_MAX_DEPTH] */
+  RTGS_EDEPTH = -2,      /* depth < 1, or > RTGS_MAX_DEPTH without the per-pixel state buffers */
   RTGS_EWORKSPACE = -3,  /* workspace smaller than rtgs_workspace_bytes() */
   RTGS_ELAUNCH = -4,     /* hipGetLastError() after a launch was not hipSuccess */
   RTGS_EDEVICE = -5      /* no usable gfx950 device / runtime error */
@@ -92,7 +92,9 @@ typedef struct RtgsCamera {
 #define RTGS_TRACE_SPLIT_OFF 16u
 
 typedef struct RtgsTraceParams {
-  int32_t depth;        /* peels performed by this call, 1..RTGS_MAX_DEPTH               */
+  int32_t depth;        /* peels performed by this call, >= 1.  Above RTGS_MAX_DEPTH the call  */
+                        /* is a chain of ceil(depth/16) launches through attenuation_buf and  */
+                        /* ray_start (both required then; one projection serves the chain)   */
   float t_cutoff;       /* transmittance early-out of the compositing loop; 0 = disabled  */
                         /* (the reference has none)                                       */
   int32_t tile_first;   /* this shard renders macro-tiles tile_first, +tile_step, ...     */
@@ -148,7 +150,7 @@ int32_t rtgs_num_local_tiles(int32_t width, int32_t height, int32_t tile_first, 
  *   kind 1  the same inside 8 equal-count image wedges, dealt out so that workgroup b -- which the
  *           dispatcher hands to XCD b % 8 -- renders a tile of wedge b % 8: each XCD's 4 MiB L2 then
  *           serves the Gaussians of one eighth of the screen (k_trace c3 0.139 -> 0.135 ms, with SH
- *           0.310 -> 0.289).  What rtgs.RayTracer uses. */
+ *           0.310 -> 0.289).  What rtgs.RayTracer and the tile-parallel renderer use. */
 int32_t rtgs_launch_order(int32_t width, int32_t height, int32_t tile_first, int32_t tile_step, int32_t kind,
                           int32_t* order);
 
@@ -161,7 +163,13 @@ int32_t rtgs_launch_order(int32_t width, int32_t height, int32_t tile_first, int
  *   attenuation_buf  [W][H]     in (RESUME) / out; may be NULL without RESUME
  *   ray_start        &rays[0][0][6] with stride 8 floats, i.e. cam_ray_field[i,j].start,
  *                    in (RESUME) / out (t1 of the last peel + 1e-8, or +inf after a miss);
- *                    may be NULL without RESUME.  ray_start_stride in floats (8 for a Ray
+ *                    may be NULL without RESUME and depth <= RTGS_MAX_DEPTH.  Exact fp32 ties in
+ *                    t1 (the reference composites one of them, scene.py:433 after
+ *                    ray_tracer.py:101) each take one of the 16 list slots of a launch: a pixel
+ *                    with such a tie among its 16 nearest composites 15 distinct entries per
+ *                    launch instead of 16 (a few dozen pixels of a 1080p frame; at smaller depths
+ *                    the launch walks on through its slots) and resumes behind the list's last
+ *                    entry, so a chain loses no Gaussian, only that pixel's last peel.  ray_start_stride in floats (8 for a Ray
  *                    field, 1 for a plain [W][H] plane).
  * Runs the per-frame projection (rtgs_project) first unless `projected` is non-zero. */
 int rtgs_trace(const RtgsScene* scene, const RtgsCamera* cam, const RtgsTraceParams* params,

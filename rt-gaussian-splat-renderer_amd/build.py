@@ -16,10 +16,27 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "rtgs", "_lib", "librtgs_hip.so")
+# the same sources with -DRTGS_COUNT=1: candidate / hit / insertion counters for bench.py's honesty
+# columns (roofline.tests_executed, cull_rate); never timed, never loaded by the rtgs package
+COUNT_LIB = os.path.join(HERE, "rtgs", "_lib", "librtgs_hip_count.so")
 ORACLE_SRC = os.path.join(ROOT, "oracle", "rtgs_oracle.c")
 ORACLE_LIB = os.path.join(ROOT, "oracle", "_build", "librtgs_oracle.so")
 
 HIP_SOURCES = ["rtgs_trace.hip", "rtgs_ops.hip"]
+
+
+def source_hash() -> str:
+    """sha256 (16 hex digits) of everything librtgs_hip.so is compiled from: csrc/* and
+    include/rtgs_hip.h.  Stored in the profile summaries under profiles/ so that bench.py can tell
+    whether a committed counter belongs to the build it is timing."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".h")))
+    for f in files + [os.path.join(ROOT, "include", "rtgs_hip.h")]:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def _newer(target, deps):
@@ -34,17 +51,44 @@ def _run(cmd):
     subprocess.run(cmd, check=True)
 
 
-def build_hip(force: bool = False, extra_flags=()) -> str:
-    """hipcc --offload-arch=gfx950 -> rtgs/_lib/librtgs_hip.so (cross-compiles without a GPU)."""
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+def _hip_deps():
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.join(CSRC, "rtgs_common.hpp"), os.path.join(ROOT, "include", "rtgs_hip.h")]
-    if not force and _newer(LIB, deps):
-        return LIB
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    return srcs, srcs + [os.path.join(CSRC, "rtgs_common.hpp"), os.path.join(ROOT, "include", "rtgs_hip.h")]
+
+
+def _stamp_ok(target) -> bool:
+    """The library was built from exactly these sources (hash stamp beside it) -- mtimes alone say
+    nothing after a checkout or a snapshot copy."""
+    try:
+        with open(target + ".srchash") as f:
+            return f.read().strip() == source_hash() and os.path.exists(target)
+    except OSError:
+        return False
+
+
+def _hipcc(out, extra_flags=()):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    srcs, _ = _hip_deps()
+    os.makedirs(os.path.dirname(out), exist_ok=True)
     _run([hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, *extra_flags, *srcs, "-o", LIB])
+          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, *extra_flags, *srcs, "-o", out])
+    with open(out + ".srchash", "w") as f:
+        f.write(source_hash() + "\n")
+
+
+def build_hip(force: bool = False, extra_flags=()) -> str:
+    """hipcc --offload-arch=gfx950 -> rtgs/_lib/librtgs_hip.so (cross-compiles without a GPU).
+    Skipped only when the source-hash stamp written by the last build matches the tree."""
+    if force or extra_flags or not _stamp_ok(LIB):
+        _hipcc(LIB, extra_flags)
     return LIB
+
+
+def build_count(force: bool = False) -> str:
+    """The counting variant (see COUNT_LIB)."""
+    if force or not _stamp_ok(COUNT_LIB):
+        _hipcc(COUNT_LIB, ["-DRTGS_COUNT=1"])
+    return COUNT_LIB
 
 
 def build_oracle(force: bool = False) -> str | None:
@@ -62,4 +106,5 @@ def build_oracle(force: bool = False) -> str | None:
 if __name__ == "__main__":
     force = "--force" in sys.argv
     print(build_hip(force))
+    print(build_count(force))
     print(build_oracle(force))

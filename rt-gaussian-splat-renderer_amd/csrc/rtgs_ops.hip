@@ -561,7 +561,7 @@ const char* rtgs_strerror(int code) {
   switch (code) {
     case RTGS_OK: return "ok";
     case RTGS_EINVAL: return "invalid argument (null pointer, non-positive size or bad enum)";
-    case RTGS_EDEPTH: return "depth outside [1, RTGS_MAX_DEPTH]";
+    case RTGS_EDEPTH: return "depth < 1, or depth > RTGS_MAX_DEPTH without the per-pixel state buffers (attenuation_buf, ray_start)";
     case RTGS_EWORKSPACE: return "workspace smaller than rtgs_workspace_bytes()";
     case RTGS_ELAUNCH: return "HIP kernel launch failed";
     case RTGS_EDEVICE: return "no usable HIP device";

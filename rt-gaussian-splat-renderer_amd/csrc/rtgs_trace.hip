@@ -60,6 +60,9 @@ namespace {
 #ifndef RTGS_STAMPS
 #define RTGS_STAMPS 0     // diagnostic build: per-phase s_memtime stamps of wave 0 into the buffer
 #endif                    // passed as attenuation_buf (8 x u64 per block); never quote its run time
+#ifndef RTGS_COUNT
+#define RTGS_COUNT 0      // counting build (librtgs_hip_count.so, bench.py's honesty columns): every wave adds its
+#endif                    // candidate / hit / insertion counts to device counters read by rtgs_debug_counters()
 #ifndef RTGS_ABLATE
 #define RTGS_ABLATE 0     // timing-only builds (wrong images): 1 no insertion, 2 no hit path,
 #endif                    // 3 no per-candidate loop, 4 no slab expansion either
@@ -211,6 +214,13 @@ struct TraceArgs {
   const int32_t* bin_list;    // [supertiles][bin_stride]
   int32_t bin_stride, bin_shift, bin_sx;
 };
+
+#if RTGS_COUNT
+// [0] candidates a wave evaluated (x 64 lanes = ray-Gaussian conic tests executed), [1] of those with a hit
+// in some lane, [2] insertion-network runs, [3] lanes with a valid hit, [4] lanes that inserted,
+// [5] Gaussian bounds tested by the expansion (lanes), [6] slab bounds tested (lanes), [7] waves
+__device__ unsigned long long g_count[8];
+#endif
 
 // ------------------------------------------------------------------------------------
 // per-frame projection
@@ -432,7 +442,9 @@ __global__ __launch_bounds__(256) void k_project(int32_t n, const float* __restr
                         (double)rot[4 * g + 2] * rot[4 * g + 2] + (double)rot[4 * g + 3] * rot[4 * g + 3];
       const double smax = fmax(fabs((double)scale[3 * g]), fmax(fabs((double)scale[3 * g + 1]), fabs((double)scale[3 * g + 2])));
       const double lo = sqrt(mx * mx + my * my + mz * mz) - 1.7320508075688774 * k2 * smax;
-      tmin[g] = lo > 0.0 ? (float)(lo * (1.0 - 1e-6)) : 0.f;   // NaN -> 0: never skipped
+      // (1e-4 relative: the t1 it stands in for is evaluated per ray in fp32 with v_rcp / v_sqrt on
+      // fp32-rounded record coefficients, a few 1e-7 relative; the bound must stay below THAT value)
+      tmin[g] = lo > 0.0 ? (float)(lo * (1.0 - 1e-4)) : 0.f;   // NaN -> 0: never skipped
     }
     bbox[g] = bb;
     float4* out = reinterpret_cast<float4*>(rec + (size_t)g * kRecFloats);
@@ -877,6 +889,9 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   const int nslabs = (a.n + kSlab - 1) / kSlab;
   // depth keys live behind the slab and group bounds (see slab_key_of)
   const float* const slab_key = reinterpret_cast<const float*>(slab_bbox + nslabs + (nslabs + kSuper - 1) / kSuper);
+#if RTGS_COUNT
+  unsigned n_iter = 0, n_pass = 0, n_ins = 0, n_hit_lanes = 0, n_ins_lanes = 0, n_exp = 0, n_scan = 0;
+#endif
 #if RTGS_STAMPS
   unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
   int c_iter = 0, c_hit = 0, c_ins = 0, c_slabs = 0;
@@ -951,6 +966,9 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
       sk[it] = 0.f;
       if (sl < nslabs) { sb[it] = slab_bbox[sl]; sk[it] = slab_key[sl]; }
     }
+#if RTGS_COUNT
+    n_scan += (unsigned)kSlabIters * kWave;
+#endif
     unsigned long long keep_m[kSlabIters];
     int wcnt = 0;
 #pragma unroll
@@ -1045,6 +1063,9 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
                               gbase[q] + lane < a.n;
             const unsigned long long gm = __ballot(keep);
             const int c = __popcll(gm);
+#if RTGS_COUNT
+            n_exp += kWave;
+#endif
             if (rcnt + c > kRegionCap) {
               full = true;   // this slab opens the next round
             } else {
@@ -1172,6 +1193,9 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
           while (m) {
             const int b = __builtin_ctzll(m);
             asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(b));   // m &= m - 1 in one SALU
+#if RTGS_COUNT
+            ++n_iter;
+#endif
 #if RTGS_STAMPS
             ++c_iter;
             t_loop0 = __builtin_amdgcn_s_memtime();
@@ -1224,6 +1248,9 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
             continue;
 #endif
             if ((__builtin_amdgcn_ballot_w64(e > 0.f) & img_m) == 0ull) continue;
+#if RTGS_COUNT
+            ++n_pass;
+#endif
 #if RTGS_STAMPS
             ++c_hit;
 #endif
@@ -1245,6 +1272,11 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
             const bool cand = hit && t1 > start;
             const unsigned kn = cand ? __float_as_uint(t1) : ~0u;
             const bool ins = kn < key[kK - 1];
+#if RTGS_COUNT
+            n_hit_lanes += (unsigned)__popcll(__ballot(cand));
+            n_ins_lanes += (unsigned)__popcll(__ballot(ins));
+            if (wave_any(ins)) ++n_ins;
+#endif
             if (wave_any(ins)) {
 #if RTGS_STAMPS
               ++c_ins;
@@ -1530,8 +1562,18 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
     }
   }
 
+#if RTGS_COUNT
+  if (lane == 0) {
+    const unsigned v[8] = {n_iter, n_pass, n_ins, n_hit_lanes, n_ins_lanes, n_exp, n_scan, 1u};
+    for (int k = 0; k < 8; ++k) atomicAdd(&g_count[k], (unsigned long long)v[k]);
+  }
+#endif
   if (ea->flags & RTGS_TRACE_COMPACT) {
     float* o = ea->sample + ((size_t)ltile * kTile * kTile + (size_t)(pi_e - mi0) * kTile + (pj_e - mj0)) * 3;
+    if (ea->flags & RTGS_TRACE_ACCUMULATE) {
+      const Rgb old = *reinterpret_cast<const Rgb*>(o);
+      L0 += old.r; L1 += old.g; L2 += old.b;
+    }
     *reinterpret_cast<Rgb*>(o) = Rgb{L0, L1, L2};   // one 12-B store per lane
   } else if (in_img) {
     float* o = ea->sample + pix * 3;
@@ -1560,8 +1602,18 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
 #if !RTGS_STAMPS
     if (ea->att) ea->att[pix] = T;
 #endif
-    // ray_tracer.py:99-104: start = t1 + EPS after a hit, +inf after a miss
-    if (ea->start) ea->start[pix * ea->start_stride] = (nhit == ea->depth) ? last_t + 1e-8f : kInf;
+    // ray_tracer.py:99-104: start = t1 + EPS after a hit, +inf after a miss.  A list that is FULL
+    // although fewer than `depth` distinct entries were composited lost slots to exact t1 ties: the
+    // ray has not missed -- the next peel (a resumed launch: depth > RTGS_MAX_DEPTH is a chain of
+    // them) goes on behind the list's last entry.  A ray below the cut-off has stopped for good.
+    if (ea->start) {
+      float s_out = (nhit == ea->depth) ? last_t + 1e-8f : kInf;
+      if constexpr (kK > 1) {
+        if (nhit < ea->depth && key[kK - 1] < kEmpty && !(ea->t_cutoff > 0.f && T < ea->t_cutoff))
+          s_out = __uint_as_float(key[kK - 1]) + 1e-8f;
+      }
+      ea->start[pix * ea->start_stride] = s_out;
+    }
   }
 }
 
@@ -1775,7 +1827,26 @@ static int trace_impl(const RtgsScene* scene, const RtgsCamera* cam, const RtgsT
                       int32_t projected, int32_t tile_limit, rtgs_stream_t stream) {
   if (!params || !sample_buf) return RTGS_EINVAL;
   if (int rc = validate(scene, cam, workspace, workspace_bytes)) return rc;
-  if (params->depth < 1 || params->depth > RTGS_MAX_DEPTH) return RTGS_EDEPTH;
+  if (params->depth < 1) return RTGS_EDEPTH;
+  if (params->depth > RTGS_MAX_DEPTH) {
+    // The reference's depth is unbounded (__main__.py:66-71: one peel per sample() call, as many
+    // as asked for).  A launch keeps RTGS_MAX_DEPTH entries per ray; more peels are a CHAIN of
+    // launches through the per-pixel state -- each resumes behind the last entry of the one before
+    // (ray.start, attenuation) and accumulates into the same image, exactly the reference's loop
+    // cut into runs of 16.  Needs the state buffers; one projection serves the whole chain.
+    if (!attenuation_buf || !ray_start) return RTGS_EDEPTH;
+    RtgsTraceParams p = *params;
+    int32_t left = params->depth;
+    for (int32_t link = 0; left > 0; ++link) {
+      p.depth = left > RTGS_MAX_DEPTH ? RTGS_MAX_DEPTH : left;
+      if (link > 0) p.flags |= RTGS_TRACE_RESUME | RTGS_TRACE_ACCUMULATE;
+      if (int rc = trace_impl(scene, cam, &p, sample_buf, attenuation_buf, ray_start, ray_start_stride,
+                              workspace, workspace_bytes, link > 0 ? 1 : projected, tile_limit, stream))
+        return rc;
+      left -= p.depth;
+    }
+    return RTGS_OK;
+  }
   if (params->tile_step <= 0 || params->tile_first < 0 || !(params->t_cutoff >= 0.f)) return RTGS_EINVAL;
   if ((params->flags & RTGS_TRACE_RESUME) && (!attenuation_buf || !ray_start)) return RTGS_EINVAL;
   if (ray_start && ray_start_stride <= 0) return RTGS_EINVAL;
@@ -1887,6 +1958,19 @@ int rtgs_render(const RtgsScene* scene, const RtgsCamera* cam, int32_t depth, fl
   return trace_impl(scene, cam, &p, sample_out, transmittance_out, nullptr, 1, workspace, workspace_bytes,
                     0, (tile_y1 - tile_y0) * tiles_x, stream);
 }
+
+#if RTGS_COUNT
+// counting build only (not part of include/rtgs_hip.h): copy the 8 counters to the host, optionally zero them
+int rtgs_debug_counters(unsigned long long* host_out, int32_t reset) {
+  if (hipDeviceSynchronize() != hipSuccess) return RTGS_EDEVICE;
+  if (host_out && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_count), sizeof(g_count)) != hipSuccess) return RTGS_EDEVICE;
+  if (reset) {
+    const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_count), z, sizeof(z)) != hipSuccess) return RTGS_EDEVICE;
+  }
+  return RTGS_OK;
+}
+#endif
 
 int rtgs_untile(const float* compact, int32_t world, int32_t tiles_per_rank, int32_t width,
                 int32_t height, float* image, rtgs_stream_t stream) {

@@ -95,23 +95,29 @@ class RtgsError(RuntimeError):
     """A negative return code from the C ABI."""
 
 
+def load_library(path: str, extra: dict | None = None) -> ctypes.CDLL:
+    """dlopen a build of the library and attach the prototypes (every symbol of include/rtgs_hip.h
+    must resolve; `extra` adds build-specific ones, e.g. the counting build's rtgs_debug_counters)."""
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: build it with `python __graft_entry__.py build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    handle = ctypes.CDLL(path)
+    for name, (restype, argtypes) in {**PROTOTYPES, **(extra or {})}.items():
+        fn = getattr(handle, name)  # AttributeError = missing export
+        fn.restype = restype
+        fn.argtypes = argtypes
+    got = handle.rtgs_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError(f"{os.path.basename(path)} ABI {got} != binding ABI {ABI_VERSION}")
+    return handle
+
+
 def lib() -> ctypes.CDLL:
     """Load librtgs_hip.so (once).  Raises if it has not been built."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError(
-                f"{LIB_PATH} is missing: build it with `python __graft_entry__.py build` "
-                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
-        handle = ctypes.CDLL(LIB_PATH)
-        for name, (restype, argtypes) in PROTOTYPES.items():
-            fn = getattr(handle, name)  # AttributeError = missing export
-            fn.restype = restype
-            fn.argtypes = argtypes
-        got = handle.rtgs_abi_version()
-        if got != ABI_VERSION:
-            raise RuntimeError(f"librtgs_hip.so ABI {got} != binding ABI {ABI_VERSION}")
-        _lib = handle
+        _lib = load_library(LIB_PATH)
     return _lib
 
 

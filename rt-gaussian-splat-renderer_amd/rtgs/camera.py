@@ -50,9 +50,20 @@ class Camera:
 
     def generate_ray_field(self, position, rotation) -> None:
         """Fill ``cam_ray_field`` with one ray per pixel centre (camera.py:57-71)."""
-        cam = self.native(position, rotation)
-        nat.check(nat.lib().rtgs_generate_rays(cam, nat.ptr(self.cam_ray_field.data), nat.stream()),
-                  "rtgs_generate_rays")
+        self._generate(position, rotation)
+        self.cam_ray_field.defer(None, False)      # up to date; supersedes any deferred update
         self.field_position = vec3(position)
         self.field_rotation = vec4(rotation)
-        self.cam_ray_field.mark_edited(False)
+
+    def _generate(self, position, rotation) -> None:
+        cam = self.native(position, rotation)
+        nat.check(nat.lib().rtgs_generate_rays(cam, nat.ptr(self.cam_ray_field.storage), nat.stream()),
+                  "rtgs_generate_rays")
+
+    def defer_ray_field(self, position, rotation, update, state_deferred: bool) -> None:
+        """What ``RayTracer`` calls instead of ``generate_ray_field`` at the start of a sample: the
+        field *logically* holds the rays of this pose from now on, but its 32 B per pixel are only
+        rewritten (by ``update``) when somebody reads or edits it (``RayField`` docstring)."""
+        self.cam_ray_field.defer(update, state_deferred)
+        self.field_position = vec3(position)
+        self.field_rotation = vec4(rotation)

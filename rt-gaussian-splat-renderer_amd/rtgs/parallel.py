@@ -7,8 +7,9 @@ are dealt round-robin
 are replicated) and renders its tiles into a compact [tiles_per_rank, T, T, 3] buffer, and ONE
 exchange step -- a ``torch.distributed`` gather (backend "nccl" == RCCL over xGMI) of
 W*H*12/world bytes per rank -- lands the shards on the destination rank, where ``rtgs_untile``
-de-interleaves them into the (W, H, 3) framebuffer.  Frames are double-buffered: the gather of
-frame f overlaps the trace of frame f+1 on the ranks that are not the destination.
+de-interleaves them into the (W, H, 3) framebuffer.  Every rank keeps F frames in flight
+(``TileParallelRenderer``, default 2): frame f is traced on render stream f mod F while the gather of
+the frames before it runs on the caller's stream.
 """
 
 from __future__ import annotations
@@ -76,6 +77,7 @@ class HipBackend:
         need = nat.lib().rtgs_workspace_bytes(scene.num_gaussians)
         self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
         self._orders = {}
+        self._state = {}
         # Optional hipGraph replay of project + trace (RTGS_GRAPH=1).  OFF by default: measured on
         # MI355X / ROCm 7.2 (tools/graph_vs_direct.py) a replay costs 12 us more per frame than the
         # two direct launches and holds the host until the graph has run (c3 1/8 shard: 70.9 vs
@@ -121,8 +123,14 @@ class HipBackend:
             flags |= nat.TRACE_SPLIT_ON if split else nat.TRACE_SPLIT_OFF
         params = nat.RtgsTraceParams(self.depth, self.t_cutoff, tile_first, tile_step, flags,
                                      nat.ptr(order))
+        att = start = None
+        if self.depth > nat.MAX_DEPTH:
+            # a chain of launches through per-pixel state (rtgs_hip.h, RtgsTraceParams.depth): one
+            # (attenuation, ray.start) pair per workspace, i.e. per frame in flight
+            att, start = self._state.setdefault(ws.data_ptr(), (self.alloc(self.width, self.height),
+                                                                 self.alloc(self.width, self.height)))
         nat.check(nat.lib().rtgs_trace(self.scene.native(), self.camera.native(), params,
-                                       nat.ptr(out), None, None, 1, nat.ptr(ws), ws.numel(),
+                                       nat.ptr(out), nat.ptr(att), nat.ptr(start), 1, nat.ptr(ws), ws.numel(),
                                        1 if projected else 0, st),
                   "rtgs_trace")
 
@@ -138,15 +146,16 @@ class HipBackend:
             self._graphs[key] = g
         return g
 
-    def render(self, out, tile_first: int, tile_step: int, compact: bool, stream=None):
+    def render(self, out, tile_first: int, tile_step: int, compact: bool, stream=None, workspace=None):
         """project + trace of one shard into `out`: two direct launches on `stream` (default: the
-        current stream), or -- opt-in, current stream only -- a graph replay / the pipelined form."""
+        current stream) with `workspace` (default: the backend's own), or -- opt-in, current stream
+        only -- a graph replay / the pipelined form."""
         if stream is None and self.use_graph:
             self.frame_graph(out, tile_first, tile_step, compact).replay()
         elif stream is None and self.pipeline:
             self._render_pipelined(out, tile_first, tile_step, compact)
         else:
-            self.trace(out, tile_first, tile_step, compact, stream=stream)
+            self.trace(out, tile_first, tile_step, compact, stream=stream, workspace=workspace)
 
     def _render_pipelined(self, out, tile_first: int, tile_step: int, compact: bool):
         """project on a side stream into workspace f & 1, trace on the caller's stream once that
@@ -234,10 +243,20 @@ class _FrameGraph:
 
 
 class TileParallelRenderer:
-    """Renders whole frames on `world` ranks; the image lands in ``framebuffer`` on rank `dst`."""
+    """Renders whole frames on `world` ranks; the image lands in ``framebuffer`` on rank `dst`.
+
+    ``frames_in_flight`` (default 2, ``RTGS_FRAMES_IN_FLIGHT``): a 1/8 shard of a 1080p frame is ONE
+    resident round of workgroups, so its trace takes as long as its heaviest tile's dependency chain
+    (37 us at c3 whether the shard is 1/8 or 1/16 of the frame) and most of the chip idles behind it.
+    With F frames in flight every rank alternates its frames over F render streams, each with its
+    own workspace, so consecutive frames' traces overlap (two 1/8-shard traces: 43.5 us per pair
+    against 74.3 one after the other, tools/concurrency_probe.py) and the loop is bound by
+    throughput, not by one tile's latency.  Each frame still costs its render stream exactly one
+    event record; the gather and the untile stay on the caller's stream, in frame order."""
 
     def __init__(self, scene=None, camera=None, depth: int = 16, rank: int = 0, world: int = 1,
-                 t_cutoff: float = 0.0, dst: int = 0, group=None, backend=None, gather_fn=None):
+                 t_cutoff: float = 0.0, dst: int = 0, group=None, backend=None, gather_fn=None,
+                 frames_in_flight: int | None = None):
         self.backend = backend if backend is not None else HipBackend(scene, camera, depth, t_cutoff)
         self._gather = gather_fn if gather_fn is not None else dist.gather   # injectable for tests
         self.rank, self.world, self.dst, self.group = int(rank), int(world), int(dst), group
@@ -247,85 +266,116 @@ class TileParallelRenderer:
         self.tiles_per_rank = (self.total_tiles + self.world - 1) // self.world
         self.local_tiles = local_tile_count(self.total_tiles, self.rank, self.world)
         self.framebuffer = b.alloc(b.width, b.height, 3) if (self.world == 1 or self.rank == self.dst) else None
-        self._pending = None
+        if frames_in_flight is None:
+            frames_in_flight = int(os.environ.get("RTGS_FRAMES_IN_FLIGHT", "2"))
+        if frames_in_flight < 1:
+            raise ValueError("frames_in_flight must be >= 1")
+        self.frames_in_flight = int(frames_in_flight) if self.world > 1 else 1
+        self._pending = []          # one-stream form: (work, slot) of the gathers not yet completed
         self._frame = 0
         self._comm = None
         if self.world > 1:
+            F = self.frames_in_flight
+            streams = isinstance(b, HipBackend) and os.environ.get("RTGS_RENDER_STREAM", "1") != "0"
+            # buffer ring.  Two-stream form: 2 F slots, so that a render stream never waits for the
+            # gather of the frame it traced last (only for the one before that, long done);
+            # one-stream form: at most F gathers are outstanding, F slots
+            self._slots = 2 * F if streams else max(F, 2)
             shard = (self.tiles_per_rank, self.TILE, self.TILE, 3)
-            self.compact = [b.alloc(*shard), b.alloc(*shard)]
-            self.gathered = ([b.alloc(self.world, *shard), b.alloc(self.world, *shard)]
-                             if self.rank == self.dst else [None, None])
+            self.compact = [b.alloc(*shard) for _ in range(self._slots)]
+            n_g = (2 if streams else self._slots) if self.rank == self.dst else 0
+            # (two-stream form: gather and untile of consecutive frames are serial on the caller's
+            # stream, two landing buffers are plenty; one-stream form: one per outstanding gather)
+            self.gathered = [b.alloc(self.world, *shard) for _ in range(n_g)]
             # the per-rank views torch.distributed.gather wants, made once (8 views cost ~8 us per frame)
-            self._glist = [list(g.unbind(0)) if g is not None else None for g in self.gathered]
-            if isinstance(b, HipBackend) and os.environ.get("RTGS_RENDER_STREAM", "1") != "0":
-                # Two streams: the shard is rendered on a stream of its own (handed to the C ABI as
-                # an argument, never made current), the gather and the untile stay on the caller's
-                # stream.  Neither waits for the other's current frame -- only for the buffer it is
-                # about to reuse -- and the collective can be issued in its blocking form, which
+            self._glist = [list(g.unbind(0)) for g in self.gathered]
+            if streams:
+                # F + 1 streams: the shards are rendered on streams of their own (handed to the C ABI
+                # as an argument, never made current), the gather and the untile stay on the caller's
+                # stream.  Neither side waits for the other's current frame -- only for the buffer it
+                # is about to reuse -- and the collective can be issued in its blocking form, which
                 # costs the host 16 us instead of the 28 us of async_op=True + wait()
                 # (tools/host_overhead.py)
-                self._comm = dict(render=torch.cuda.Stream(device=b.device),
-                                  traced=[torch.cuda.Event(), torch.cuda.Event()],
-                                  sent=[torch.cuda.Event(), torch.cuda.Event()])
+                self._comm = dict(render=[torch.cuda.Stream(device=b.device) for _ in range(F)],
+                                  ws=[b.workspace] + [torch.empty_like(b.workspace) for _ in range(F - 1)],
+                                  traced=[torch.cuda.Event() for _ in range(self._slots)],
+                                  sent=[torch.cuda.Event() for _ in range(self._slots)],
+                                  seen=[None] * F)
 
     # ---- frame loop ------------------------------------------------------------------------
+    def _scene_key(self):
+        """Changes when work queued on the CALLER's stream may have written what the render streams
+        read: a re-commit, or an in-place edit of a streamed tensor (torch bumps ``_version``)."""
+        sc = self.backend.scene
+        sh = sc.sh
+        return (sc.version, sc.position._version, sc.rotation._version, sc.scale._version,
+                sc.color_opacity._version, -1 if sh is None else sh._version)
+
     def render_frame(self) -> None:
         """Queue one frame.  world == 1: straight into ``framebuffer``.  world > 1: trace this
-        rank's tiles into one of two compact buffers on the render stream, gather them (and, on
-        rank dst, untile) on the caller's stream while the render stream goes on with the next
-        frame: ``framebuffer`` is complete in the caller's stream order.  (Without a HIP backend
-        -- the CPU tests' stand-in -- or with RTGS_RENDER_STREAM=0: one stream; start the gather,
-        then complete the previous frame.)"""
+        rank's tiles into a slot of the compact-buffer ring on render stream f mod F, gather them
+        (and, on rank dst, untile) on the caller's stream while the render streams go on with the
+        next frames: ``framebuffer`` is complete in the caller's stream order.  (Without a HIP
+        backend -- the CPU tests' stand-in -- or with RTGS_RENDER_STREAM=0: one stream; start the
+        gather, then complete the oldest outstanding frame once F are in flight.)"""
         b = self.backend
         if self.world == 1:
             b.render(self.framebuffer, 0, 1, compact=False)
             return
-        k = self._frame & 1
+        f = self._frame
         self._frame += 1
-        glist = self._glist[k]
+        k = f % self._slots
         if self._comm is not None:
             cm = self._comm
-            rs = cm["render"]
+            s = f % self.frames_in_flight
+            rs = cm["render"][s]
             cur = b.nat.current_stream(b.device.index)    # the caller's stream
-            if cm.get("scene_version") != b.scene.version:
-                rs.wait_stream(cur)                # scene uploads / edits queued there
-                cm["scene_version"] = b.scene.version
-            # the gather two frames back has read compact[k].  (Guarding the reuse from the host
+            key = self._scene_key()
+            if cm["seen"][s] != key:
+                rs.wait_stream(cur)                # scene uploads / edits queued on the caller's stream
+                cm["seen"][s] = key
+            # the gather 2 F frames back has read compact[k].  (Guarding the reuse from the host
             # instead -- event.synchronize() on a ring of 2 or 4 buffers -- keeps this barrier packet
             # off the render stream but blocks a host that runs ahead, every frame: 79 / 73 us per
             # frame against 67.)
             if not cm["sent"][k].query():          # usually long done: then the render stream is spared the packet
                 rs.wait_event(cm["sent"][k])
             if self.local_tiles:
-                b.render(self.compact[k], self.rank, self.world, compact=True, stream=rs)
+                b.render(self.compact[k], self.rank, self.world, compact=True, stream=rs, workspace=cm["ws"][s])
             cm["traced"][k].record(rs)
             cur.wait_event(cm["traced"][k])        # gather this frame's shard once it is traced
-            self._gather(self.compact[k], gather_list=glist, dst=self.dst, group=self.group,
-                         async_op=False)
+            g = f & 1
+            self._gather(self.compact[k], gather_list=self._glist[g] if self._glist else None, dst=self.dst,
+                         group=self.group, async_op=False)
             cm["sent"][k].record(cur)
             if self.rank == self.dst:
-                b.untile(self.gathered[k], self.world, self.tiles_per_rank, self.framebuffer,
+                b.untile(self.gathered[g], self.world, self.tiles_per_rank, self.framebuffer,
                          stream=cur)
             return
         if self.local_tiles:
             b.render(self.compact[k], self.rank, self.world, compact=True)
-        work = self._gather(self.compact[k], gather_list=glist, dst=self.dst, group=self.group,
-                            async_op=True)
-        prev, self._pending = self._pending, (work, k)
-        self._complete(prev)
+        work = self._gather(self.compact[k], gather_list=self._glist[k] if self._glist else None, dst=self.dst,
+                            group=self.group, async_op=True)
+        self._pending.append((work, k))
+        while len(self._pending) >= max(self.frames_in_flight, 2):
+            self._complete(self._pending.pop(0))
 
     def _complete(self, pending) -> None:
-        if pending is None:
-            return
         work, k = pending
         work.wait()
         if self.rank == self.dst:
             self.backend.untile(self.gathered[k], self.world, self.tiles_per_rank, self.framebuffer)
 
     def finish(self) -> None:
-        """Drain the pipeline: after this ``framebuffer`` on rank dst holds the last frame."""
-        prev, self._pending = self._pending, None
-        self._complete(prev)
+        """Drain the pipeline: after this ``framebuffer`` on rank dst holds the last frame (in the
+        caller's stream order) and the render streams have nothing queued that the caller's stream
+        has not waited for -- buffers may be released, the scene re-committed."""
+        while self._pending:
+            self._complete(self._pending.pop(0))
+        if self._comm is not None:
+            cur = self.backend.nat.current_stream(self.backend.device.index)
+            for rs in self._comm["render"]:
+                cur.wait_stream(rs)
 
     # ---- pieces, for measurement -----------------------------------------------------------
     def project_only(self) -> None:

@@ -70,28 +70,72 @@ class RayField:
     torch write through ``.data`` or the component views (``field.start[...] = x``), which bumps
     the tensor's version counter.  A new field is edited: zeros are not camera rays.  The HIP
     kernels write through raw pointers and do not count.  ``RayTracer.sample_step`` picks its
-    kernel by it."""
+    kernel by it.
+
+    **Lazy contents.**  The screen-space kernels generate camera rays in registers and never read
+    the origin / direction of this field, so ``RayTracer`` does not rewrite its 32 B per pixel for
+    every sample (camera.py:57-71 does, 66 MB at 1080p): it *defers* the update (``defer``) and the
+    field brings itself up to date the first time anybody looks -- ``.data``, a component view,
+    element access, ``to_numpy``, ``get``.  What a reader sees is exactly what the eager calls would
+    have left.  Code that only needs the storage (the kernels' raw pointers) uses ``storage``."""
 
     def __init__(self, shape, data: torch.Tensor | None = None):
         self.shape = (shape,) if isinstance(shape, int) else tuple(int(s) for s in shape)
         if data is None:
             data = torch.zeros(self.shape + (nat.RAY_FLOATS,), dtype=torch.float32,
                                device=nat.device())
-        self.data = nat.require_device(data, "ray field")
+        self._data = nat.require_device(data, "ray field")
         self._edited = True     # not (yet) a generated camera ray field
-        self._clean_version = self.data._version
+        self._clean_version = self._data._version
+        self._pending = None    # deferred update: callable that brings the tensor up to date
+        self.state_deferred = False   # the deferred update also owes the .start column (and the tracer's attenuation)
+
+    # ---- deferred updates -----------------------------------------------------------------
+    @property
+    def storage(self) -> torch.Tensor:
+        """The tensor WITHOUT bringing it up to date (raw-pointer users: the HIP kernels)."""
+        return self._data
+
+    @property
+    def data(self) -> torch.Tensor:
+        self.materialise()
+        return self._data
+
+    @data.setter
+    def data(self, value: torch.Tensor) -> None:
+        self._pending, self.state_deferred = None, False
+        self._data = nat.require_device(value, "ray field")
+        self.mark_edited(True)
+
+    @property
+    def pending(self) -> bool:
+        return self._pending is not None
+
+    def defer(self, update, state_deferred: bool) -> None:
+        """Replace whatever update was pending by `update` (a whole-field regeneration supersedes
+        any earlier one) and mark the field clean: its *logical* contents are generated rays."""
+        self._pending, self.state_deferred = update, bool(state_deferred)
+        self.mark_edited(False)
+
+    def materialise(self) -> None:
+        if self._pending is not None:
+            update, self._pending, self.state_deferred = self._pending, None, False
+            update()
+            self.mark_edited(False)   # the update wrote through torch / raw pointers: still generated rays
 
     @property
     def edited(self) -> bool:
-        return self._edited or self.data._version != self._clean_version
+        return self._edited or self._data._version != self._clean_version
 
     @edited.setter
     def edited(self, value: bool) -> None:
         self.mark_edited(value)
 
     def mark_edited(self, edited: bool = True) -> None:
+        if edited:
+            self.materialise()   # an edit applies on top of the up-to-date contents
         self._edited = bool(edited)
-        self._clean_version = self.data._version
+        self._clean_version = self._data._version
 
     def init(self, origin=(0, 0, 0), direction=(0, 1, 0), start=0, end=math.inf):
         """Run ``Ray.init`` (ray.py:20-41) on every element."""

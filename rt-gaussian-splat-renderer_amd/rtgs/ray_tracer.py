@@ -10,6 +10,8 @@ progressive state machine of the reference's viewer loop (__main__.py:253-257) i
 
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _native as nat
@@ -29,12 +31,24 @@ class RayTracer:
         w, h = self.buf_size.x, self.buf_size.y
         # ray_tracer.py:33-37
         self.sample_buf = torch.zeros((w, h, 3), dtype=torch.float32, device=dev)
-        self.attenuation_buf = torch.zeros((w, h), dtype=torch.float32, device=dev)
+        self._attenuation = torch.zeros((w, h), dtype=torch.float32, device=dev)
         self.num_steps = 0
         self.num_samples = 0
         self.disp_buf = torch.zeros((w, h, 3), dtype=torch.float32, device=dev)
         self._workspace = None
         self._projected_for = None   # (scene version, camera pose) the workspace records belong to
+        self._orders = {}            # (tile_first, tile_step) -> device int32 launch order
+        # RTGS_TILE_ORDER as in parallel.HipBackend: 0 = tile order, centre, wedge (default)
+        self._order_mode = os.environ.get("RTGS_TILE_ORDER", "wedge")
+
+    @property
+    def attenuation_buf(self) -> torch.Tensor:
+        """ray_tracer.py:34.  After ``sample_all`` the per-pixel state (this buffer and
+        ``cam_ray_field.start``) is only written when somebody looks (``RayField``: lazy contents)."""
+        f = self.camera.cam_ray_field
+        if f.pending and f.state_deferred:
+            f.materialise()
+        return self._attenuation
 
     # ---- plumbing ------------------------------------------------------------------------
     def _ws(self) -> torch.Tensor:
@@ -43,45 +57,87 @@ class RayTracer:
             self._workspace = torch.empty(need, dtype=torch.uint8, device=self.sample_buf.device)
         return self._workspace
 
+    def _tile_order(self, tile_first: int, tile_step: int):
+        """The XCD-wedge launch order (``rtgs_launch_order``; scheduling only), cached per shard."""
+        if self._order_mode == "0":
+            return None
+        key = (tile_first, tile_step)
+        if key not in self._orders:
+            from .parallel import cost_sorted_order
+            o = cost_sorted_order(self.buf_size.x, self.buf_size.y, nat.tile_size(), tile_first, tile_step,
+                                  "centre" if self._order_mode == "centre" else "wedge")
+            self._orders[key] = torch.from_numpy(o).to(self.sample_buf.device) if o.size else None
+        return self._orders[key]
+
     def trace(self, depth: int, *, flags: int = 0, t_cutoff: float = 0.0, tile_first: int = 0,
               tile_step: int = 1, sample_buf: torch.Tensor | None = None, position=None,
-              rotation=None, projected: bool = False) -> None:
-        """One ``rtgs_trace`` launch on the current stream (see include/rtgs_hip.h)."""
+              rotation=None, projected: bool = False, state: bool = True) -> None:
+        """One ``rtgs_trace`` call on the current stream (see include/rtgs_hip.h).  ``state=False``
+        leaves ``attenuation_buf`` and ``cam_ray_field.start`` alone (NULL pointers: the kernel then
+        neither reads nor writes them); a depth above ``RTGS_MAX_DEPTH`` needs them (the library
+        chains launches through that state)."""
         ws = self._ws()
         params = nat.RtgsTraceParams(int(depth), float(t_cutoff), int(tile_first), int(tile_step),
-                                     int(flags), None)
+                                     int(flags), nat.ptr(self._tile_order(int(tile_first), int(tile_step))))
         # the per-frame projection only depends on (scene, camera pose): the 16 single-peel calls of
         # one progressive sample share it
         pos = self.camera.position if position is None else position
         rot = self.camera.rotation if rotation is None else rotation
         sc = self.scene
-        state = (id(sc), sc.version, sc.position._version, sc.rotation._version, sc.scale._version, ws.data_ptr(),
-                 tuple(float(v) for v in pos), tuple(float(v) for v in rot),
-                 tuple(float(v) for v in self.camera.focal_length))
-        if not projected and state == self._projected_for:
+        pstate = (id(sc), sc.geometry_key(), ws.data_ptr(),
+                  tuple(float(v) for v in pos), tuple(float(v) for v in rot),
+                  tuple(float(v) for v in self.camera.focal_length))
+        if not projected and pstate == self._projected_for:
             projected = True
-        self._projected_for = state
+        self._projected_for = pstate
         out = self.sample_buf if sample_buf is None else nat.require_device(sample_buf, "sample_buf")
-        rays = self.camera.cam_ray_field.data
-        start_ptr = rays.data_ptr() + 6 * 4  # &cam_ray_field[0,0].start, stride 8 floats
+        att_ptr = start_ptr = None
+        if state:
+            att_ptr = nat.ptr(self._attenuation)
+            # &cam_ray_field[0,0].start, stride 8 floats (raw storage: the kernel owns that column)
+            start_ptr = self.camera.cam_ray_field.storage.data_ptr() + 6 * 4
         nat.check(nat.lib().rtgs_trace(self.scene.native(), self.camera.native(position, rotation),
-                                       params, nat.ptr(out), nat.ptr(self.attenuation_buf),
-                                       start_ptr, nat.RAY_FLOATS, nat.ptr(ws), ws.numel(),
-                                       1 if projected else 0, nat.stream()), "rtgs_trace")
+                                       params, nat.ptr(out), att_ptr, start_ptr, nat.RAY_FLOATS,
+                                       nat.ptr(ws), ws.numel(), 1 if projected else 0, nat.stream()),
+                  "rtgs_trace")
+
+    def _pose(self):
+        return tuple(float(v) for v in self.camera.position), tuple(float(v) for v in self.camera.rotation)
+
+    def _regenerate_keeping_start(self, pos, rot) -> None:
+        """Deferred update of a ray field whose ``.start`` column is live (the peel kernels wrote
+        it): origin / direction / end of the pose the sample started from, ``.start`` untouched."""
+        f = self.camera.cam_ray_field
+        keep = f.storage[..., 6].clone()
+        self.camera._generate(pos, rot)
+        f.storage[..., 6] = keep
+
+    def _replay_state(self, pos, rot, depth: int, t_cutoff: float) -> None:
+        """Deferred update after ``sample_all``: generated rays of that pose, then the per-pixel
+        state (``.start``, attenuation) the ``depth`` peels leave, by tracing once more into a
+        scratch image."""
+        self.camera._generate(pos, rot)
+        scratch = torch.empty_like(self.sample_buf)
+        self.trace(depth, t_cutoff=t_cutoff, sample_buf=scratch, position=pos, rotation=rot)
 
     # ---- the reference's API ------------------------------------------------------------
     def sample(self, depth: int):
-        """Advance the current sample by one peel (ray_tracer.py:39-54)."""
-        if self.num_steps == 0:
-            self.clear_attenuation()
-            self.camera.generate_ray_field(self.camera.position, self.camera.rotation)
-        self.sample_step()
+        """Advance the current sample by one peel (ray_tracer.py:39-54).  The reference starts a
+        sample with ``clear_attenuation()`` + ``generate_ray_field()`` (90 MB of writes at 1080p);
+        here the first peel starts from registers (attenuation 1, start 0) and writes the state the
+        next peels resume from, and the rays themselves are regenerated only if somebody reads
+        them (``RayField``: lazy contents)."""
+        first = self.num_steps == 0
+        if first:
+            pos, rot = self._pose()
+            self.camera.defer_ray_field(pos, rot, lambda: self._regenerate_keeping_start(pos, rot), False)
+        self.sample_step(_fresh=first)
         self.num_steps += 1
         if self.num_steps >= depth:
             self.num_steps = 0
             self.num_samples += 1
 
-    def sample_step(self):
+    def sample_step(self, _fresh: bool = False):
         """Composite the next-nearest Gaussian of every pixel (ray_tracer.py:79-104), resuming
         from ``cam_ray_field.start`` / ``attenuation_buf`` and accumulating into ``sample_buf``.
 
@@ -89,10 +145,13 @@ class RayTracer:
         kernel (``rtgs_trace``); one the caller has edited (``cam_ray_field[i, j] = ray``,
         ``.init()``, ``.mark_edited()``) is traced ray by ray as the reference does, whatever the
         rays are (``rtgs_sample_step_rays``)."""
-        if self.camera.cam_ray_field.edited:
+        f = self.camera.cam_ray_field
+        if f.pending and f.state_deferred:
+            f.materialise()              # peeling on after a sample_all: the state has to exist
+        if f.edited:
             self.sample_step_rays()
             return
-        self.trace(1, flags=nat.TRACE_RESUME | nat.TRACE_ACCUMULATE,
+        self.trace(1, flags=nat.TRACE_ACCUMULATE | (0 if _fresh else nat.TRACE_RESUME),
                    position=self.camera.field_position, rotation=self.camera.field_rotation)
 
     def sample_step_rays(self, brute_force: bool = False):
@@ -104,16 +163,26 @@ class RayTracer:
         acc = None if brute_force else self.scene.accel()
         nat.check(nat.lib().rtgs_sample_step_rays_accel(self.scene.native(), nat.ptr(acc),
                                                         0 if acc is None else acc.numel(), n, nat.ptr(rays),
-                                                        nat.ptr(self.sample_buf), nat.ptr(self.attenuation_buf),
+                                                        nat.ptr(self.sample_buf), nat.ptr(self._attenuation),
                                                         nat.stream()), "rtgs_sample_step_rays")
 
     def sample_all(self, depth: int, t_cutoff: float = 0.0):
-        """Extension: one WHOLE sample (``depth`` peels) in a single launch -- the result of
-        calling ``sample(depth)`` ``depth`` times from num_steps == 0."""
+        """Extension: one WHOLE sample (``depth`` peels) in a single call -- the result of
+        calling ``sample(depth)`` ``depth`` times from num_steps == 0.  Any depth: above
+        ``RTGS_MAX_DEPTH`` (16) the library chains ceil(depth / 16) launches through the per-pixel
+        state (the reference's ``-d`` is unbounded, __main__.py:66-71).  Up to 16 the state
+        (``attenuation_buf``, ``cam_ray_field``) is not written at all unless somebody reads it
+        afterwards: the frame costs what the tile-parallel path's does."""
         if self.num_steps != 0:
             raise RuntimeError("sample_all() needs num_steps == 0 (finish the partial sample first)")
-        self.camera.generate_ray_field(self.camera.position, self.camera.rotation)
-        self.trace(depth, flags=nat.TRACE_ACCUMULATE, t_cutoff=t_cutoff)
+        depth = int(depth)
+        pos, rot = self._pose()
+        if depth <= nat.MAX_DEPTH:
+            self.trace(depth, flags=nat.TRACE_ACCUMULATE, t_cutoff=t_cutoff, state=False)
+            self.camera.defer_ray_field(pos, rot, lambda: self._replay_state(pos, rot, depth, t_cutoff), True)
+        else:
+            self.trace(depth, flags=nat.TRACE_ACCUMULATE, t_cutoff=t_cutoff)
+            self.camera.defer_ray_field(pos, rot, lambda: self._regenerate_keeping_start(pos, rot), False)
         self.num_samples += 1
 
     def clear_sample(self):
@@ -123,7 +192,7 @@ class RayTracer:
 
     def clear_attenuation(self):
         """ray_tracer.py:62-66."""
-        nat.check(nat.lib().rtgs_fill(nat.ptr(self.attenuation_buf), self.attenuation_buf.numel(),
+        nat.check(nat.lib().rtgs_fill(nat.ptr(self._attenuation), self._attenuation.numel(),
                                       1.0, nat.stream()), "rtgs_fill")
 
     def generate_disp_buffer(self, num_samples: int, num_steps: int, num_depth: int):

@@ -131,7 +131,7 @@ class Scene:
         self.version = 0            # bumped by commit(): invalidates cached projections
         self.order = None           # stream slot -> index into gaussian_field
         self.sort_spatially = True  # Morton-order the streamed copies (see morton_order)
-        self._accel = None          # (scene version, device buffer) of the arbitrary-ray structure
+        self._accel = None          # (geometry key, device buffer) of the arbitrary-ray structure
 
     # ---- construction ------------------------------------------------------------------
     @classmethod
@@ -246,16 +246,24 @@ class Scene:
         s.sh = nat.ptr(self.sh)
         return s
 
+    def geometry_key(self) -> tuple:
+        """Changes whenever the streamed geometry may have: ``commit()`` bumps ``version``; in-place
+        edits of the streamed tensors (a supported contract: ``scene.position.mul_(2)``) bump their
+        torch ``_version``.  Everything cached from the geometry (projections, ``accel``) is keyed on it."""
+        return (self.version, self.position._version, self.rotation._version, self.scale._version)
+
     def accel(self) -> torch.Tensor:
         """The structure that stands in for the reference's BVH on arbitrary-ray queries
-        (scene.py:162-404 builds it in ``load_file``; here it is built on first use and after every
-        ``commit()``): fp64 inverse covariances + world-space slab boxes, ``rtgs_accel_build``."""
-        if self._accel is None or self._accel[0] != self.version:
+        (scene.py:162-404 builds it in ``load_file``; here it is built on first use, after every
+        ``commit()`` and after an in-place edit of the streamed position / rotation / scale):
+        fp64 inverse covariances + world-space slab boxes, ``rtgs_accel_build``."""
+        key = self.geometry_key()
+        if self._accel is None or self._accel[0] != key:
             need = nat.lib().rtgs_accel_bytes(self.num_gaussians)
             buf = torch.empty(need, dtype=torch.uint8, device=self.position.device)
             nat.check(nat.lib().rtgs_accel_build(self.native(), nat.ptr(buf), buf.numel(), nat.stream()),
                       "rtgs_accel_build")
-            self._accel = (self.version, buf)
+            self._accel = (key, buf)
         return self._accel[1]
 
     def hit_batch(self, rays, brute_force: bool = False):

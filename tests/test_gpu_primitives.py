@@ -288,11 +288,11 @@ def test_accelerated_scene_hit_equals_brute_force_bit_for_bit():
             torch.cuda.synchronize()
             assert torch.equal(ia, ib) and torch.equal(ta, tb)
             assert int((ia >= 0).sum()) > 500
-    assert scene._accel is not None and scene._accel[0] == scene.version
+    assert scene._accel is not None and scene._accel[0] == scene.geometry_key()
     v = scene.version
     scene.commit()                                         # a re-committed scene rebuilds its structure
     scene.hit_batch(coherent)
-    assert scene._accel[0] == v + 1
+    assert scene._accel[0][0] == v + 1
     assert nat.lib().rtgs_closest_hit_accel(scene.native(), nat.ptr(scene.accel()), 64, 10, nat.ptr(coherent),
                                             nat.ptr(ia), nat.ptr(ta), nat.stream()) == -3
 

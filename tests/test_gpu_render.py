@@ -245,6 +245,115 @@ def test_exact_ties_do_not_use_up_peels_at_shallow_depth():
         assert np.isfinite(want["start"]).mean() > 0.2      # the full-depth case is exercised
 
 
+def test_exact_tie_at_full_depth_costs_that_pixel_one_peel():
+    # ADVICE r2 / include/rtgs_hip.h (ray_start): the documented limit of the 16-slot list.  18
+    # coaxial Gaussians, the 3rd one stored twice.  The reference composites 16 DISTINCT entry
+    # distances (#1..#16); a launch keeps the 16 nearest entries, one of them the tied twin, so it
+    # composites 15 (#1..#15) and leaves ray.start behind its list's last entry (#15), not +inf:
+    # a chained depth-17 call then goes on with #16 (16 peels in all, the reference: 17).
+    n = 18
+    pos = [(0, 0, -(2.0 + k)) for k in range(n)] + [(0, 0, -4.0)]
+    m = len(pos)
+    args = (pos, [(0.1,) * 3] * m, [(1, 1, 1)] * m, [0.1] * m)
+    tr = analytic(*args, depth=16)
+    assert float(tr.sample_buf[2, 2, 0]) == pytest.approx(1 - 0.9 ** 15, abs=5e-6)
+    assert float(tr.camera.cam_ray_field.start[2, 2]) == pytest.approx(16 - math.sqrt(3) * 0.1, rel=1e-6)
+    assert float(tr.attenuation_buf[2, 2]) == pytest.approx(0.9 ** 15, abs=5e-6)
+    tr = analytic(*args, depth=17)
+    assert float(tr.sample_buf[2, 2, 0]) == pytest.approx(1 - 0.9 ** 16, abs=5e-6)
+    assert float(tr.camera.cam_ray_field.start[2, 2]) == pytest.approx(17 - math.sqrt(3) * 0.1, rel=1e-6)
+    # and at a shallow depth nothing is lost (the launch walks on through its 16 slots)
+    tr = analytic(*args, depth=8)
+    assert float(tr.sample_buf[2, 2, 0]) == pytest.approx(1 - 0.9 ** 8, abs=5e-6)
+
+
+@pytest.mark.parametrize("depth", [17, 24, 40])
+def test_depth_beyond_16_is_a_chain_of_launches(depth):
+    # the reference's -d/--depth is unbounded (__main__.py:66-71: sample() peels once per call);
+    # rtgs_trace serves depth > RTGS_MAX_DEPTH as ceil(depth/16) launches chained through
+    # ray.start / attenuation.  Against both oracles: the literal peel loop and the C one-pass form.
+    from oracle import c_oracle
+    from oracle import rtgs_ref as ref
+    arrays = synthetic.make_scene(2500, 1.0, 77, sh=(depth == 24))
+    arrays["scale"] = (arrays["scale"] * np.float32(2.0)).astype(np.float32)
+    arrays["opacity"] = (0.25 * arrays["opacity"]).astype(np.float32)     # so that peel 40 still shows
+    cam = synthetic.bench_camera(40, 36)
+    _, _, tr = U.build(arrays, cam)
+    tr.sample_all(depth)
+    torch.cuda.synchronize()
+    assert tr.num_samples == 1 and tr.num_steps == 0
+    want = c_oracle.render(arrays, cam, depth)
+    assert (want["hits"] == depth).mean() > 0.3 and (want["hits"] > 16).mean() > 0.6
+    got = tr.sample_buf.cpu().numpy().reshape(-1, 3)
+    U.assert_parity(got, want, f"depth {depth}")
+    solid = ~want["fragile"]
+    att = tr.attenuation_buf.cpu().numpy().reshape(-1)
+    assert np.abs(att - want["attenuation"])[solid].max() <= U.PIXEL_TOL
+    start = tr.camera.cam_ray_field.start.cpu().numpy().reshape(-1)
+    assert (np.isfinite(start) == np.isfinite(want["start"]))[solid].all()
+    fin = solid & np.isfinite(start)
+    assert np.abs(start[fin] - want["start"][fin]).max() <= 1e-5
+    # the literal loop on a pixel subset (NumPy, depth peels x all Gaussians)
+    rng = np.random.default_rng(3)
+    pix = np.stack([rng.integers(0, 40, 300), rng.integers(0, 36, 300)], axis=-1).astype(np.int32)
+    osc = ref.OracleScene(**arrays)
+    peel = ref.render_peel(osc, cam["position"], cam["rotation"], cam["width"], cam["height"], cam["fx"],
+                           cam["fy"], depth=depth, pixels=pix)
+    sub = want["fragile"].reshape(40, 36)[pix[:, 0], pix[:, 1]]
+    assert np.abs(U.at(tr.sample_buf, pix) - peel["sample"])[~sub].max() <= U.PIXEL_TOL
+    # sharded chains compose to the same image, and peel-by-peel sample() agrees with the chain
+    whole = tr.sample_buf.clone()
+    tr.clear_sample()
+    for r in range(3):
+        tr.trace(depth, tile_first=r, tile_step=3)
+    assert torch.equal(tr.sample_buf, whole)
+    if depth == 17:
+        _, _, b = U.build(arrays, cam)
+        for _ in range(depth):
+            b.sample(depth)
+        torch.cuda.synchronize()
+        assert b.num_samples == 1
+        assert float((b.sample_buf - whole).abs().max()) <= 4e-6
+
+
+def test_sample_all_defers_the_per_pixel_state_until_somebody_looks():
+    # up to depth 16 sample_all neither regenerates the 32 B/pixel ray field nor
+    # writes ray.start / attenuation; a reader still sees exactly what the eager calls would have
+    # left (RayField: lazy contents), and peeling on after it resumes from that state
+    arrays, cam, depth = U.case("shallow")
+    _, camera, a = U.build(arrays, cam)
+    _, camera_b, b = U.build(arrays, cam)
+    a.sample_all(depth)
+    f = camera.cam_ray_field
+    assert f.pending and f.state_deferred and not f.edited
+    before = f.storage.clone()
+    a.sample_all(depth)                                   # a second sample: still nothing written
+    assert f.pending and torch.equal(f.storage, before)
+    for _ in range(2 * depth):
+        b.sample(depth)
+    fb = camera_b.cam_ray_field
+    assert fb.pending and not fb.state_deferred          # peels wrote .start; origin/direction are owed
+    torch.cuda.synchronize()
+    assert float((a.sample_buf - b.sample_buf).abs().max()) <= 4e-6
+    assert float((a.attenuation_buf - b.attenuation_buf).abs().max()) <= 2e-6     # first look: replayed
+    assert not f.pending
+    want = rtgs.Camera(cam["position"], cam["rotation"], (cam["width"], cam["height"]), (cam["fx"], cam["fy"]))
+    want.generate_ray_field(want.position, want.rotation)
+    for fld in (f, fb):
+        assert torch.equal(fld.data[..., :6], want.cam_ray_field.data[..., :6])
+        assert torch.equal(fld.end, want.cam_ray_field.end) and not fld.edited
+    sa, sb = f.start, fb.start
+    assert torch.equal(torch.isfinite(sa), torch.isfinite(sb)) and torch.equal(sa[torch.isfinite(sa)], sb[torch.isfinite(sb)])
+    # peeling on after a deferred sample_all == peeling on after the eager calls
+    a.sample_all(depth)
+    a.sample_step(); b_extra = b.sample_buf.clone()
+    for _ in range(depth):
+        b.sample(depth)
+    b.sample_step()
+    torch.cuda.synchronize()
+    assert float((a.sample_buf - b.sample_buf).abs().max()) <= 6e-6 and not torch.equal(b.sample_buf, b_extra)
+
+
 # ---- edited ray fields: the literal per-ray sample_step (ray_tracer.py:79-104) ----
 
 def _edited_field_case(sh):
@@ -325,6 +434,16 @@ def test_ray_field_and_scene_edits_are_noticed():
     tracer.sample_step()
     torch.cuda.synchronize()
     assert float((tracer.sample_buf - first).abs().max()) > 1e-2
+    # (d) ADVICE r2: the arbitrary-ray structure (Scene.accel) is rebuilt after such an edit too --
+    # hit_batch through it must answer like the brute-force kernel, which reads the live tensors
+    rays = camera.cam_ray_field.data
+    scene.accel()
+    scene.position[:, 1] -= 0.2
+    scene.scale.mul_(1.5)
+    idx_a, t_a = scene.hit_batch(rays)
+    idx_b, t_b = scene.hit_batch(rays, brute_force=True)
+    torch.cuda.synchronize()
+    assert bool((idx_b >= 0).any()) and torch.equal(idx_a, idx_b) and torch.equal(t_a, t_b)
 
 
 def test_per_ray_and_screen_space_sample_steps_agree_on_camera_rays():
@@ -538,7 +657,8 @@ def test_error_codes_become_exceptions():
     with pytest.raises(ValueError, match="depth"):
         tracer.trace(0)
     with pytest.raises(ValueError, match="depth"):
-        tracer.trace(17)
+        tracer.trace(17, state=False)      # a chain of launches needs the per-pixel state buffers
+    tracer.trace(17)
     with pytest.raises(ValueError):
         tracer.trace(16, tile_step=0)
     with pytest.raises(ValueError):
@@ -637,6 +757,72 @@ def test_tile_parallel_frame_loop_end_to_end(world):
     torch.cuda.synchronize()
     assert torch.equal(ranks[0].framebuffer, whole)
     assert all(r.framebuffer is None for r in ranks[1:])
+
+
+class _StreamOrderedComm:
+    """A stand-in gather for rank 0 of `world` that, like RCCL, only ORDERS its copies on the current
+    stream -- no device-wide synchronize that would paper over a missing event: the other ranks'
+    shards of every frame were rendered beforehand."""
+
+    def __init__(self, shards):
+        self.shards, self.frame = shards, 0
+
+    def gather(self, tensor, gather_list=None, dst=0, group=None, async_op=False):
+        for r, out in enumerate(gather_list):
+            out.copy_(tensor if r == 0 else self.shards[self.frame][r], non_blocking=True)
+        self.frame += 1
+        return _FakeWork()
+
+
+@pytest.mark.parametrize("in_flight", [1, 2, 3])
+def test_frames_in_flight_keep_stream_order_without_host_syncs(in_flight):
+    # VERDICT r2 #1 / ADVICE r2: F frames in flight per rank on F render streams + the caller's
+    # stream.  Seven frames with seven poses and two in-place scene edits queued on the caller's
+    # stream, NO host synchronisation in between; every frame's framebuffer (snapshotted in stream
+    # order) must equal the single-rank render of that frame's pose and scene, bit for bit.
+    from rtgs.parallel import TileParallelRenderer
+    from rtgs.utils.types import vec3
+    arrays, cam, depth = U.case("oblique")
+    scene, camera, tracer = U.build(arrays, cam)
+    world, T = 4, nat.tile_size()
+    per = (nat.lib().rtgs_num_tiles(cam["width"], cam["height"]) + world - 1) // world
+    p0 = np.asarray(cam["position"], np.float64)
+    poses = [tuple(p0 + d) for d in ((0, 0, 0), (0.2, -0.1, 0.1), (-0.15, 0.1, -0.2), (0.05, 0.2, 0.3),
+                                     (0.3, 0.0, -0.1), (-0.3, -0.2, 0.0), (0.1, 0.1, 0.1))]
+    edits = {3: 0.5, 5: 2.0}      # before frame 3 halve colour and opacity in place, before frame 5 restore
+
+    def apply(k):
+        if k in edits:
+            scene.color_opacity.mul_(edits[k])
+    want, shards = [], []
+    for k, pos in enumerate(poses):          # pass 1, synchronous: expected frames, the peers' shards
+        apply(k)
+        camera.position = vec3(pos)
+        tracer.trace(depth, state=False)
+        want.append(tracer.sample_buf.clone())
+        row = [None]
+        for r in range(1, world):
+            sh = torch.zeros((per, T, T, 3), dtype=torch.float32, device="cuda")
+            tracer.trace(depth, flags=nat.TRACE_COMPACT, tile_first=r, tile_step=world, sample_buf=sh, state=False)
+            row.append(sh)
+        shards.append(row)
+    torch.cuda.synchronize()
+    assert not torch.equal(want[2], want[3]) and not torch.equal(want[4], want[5])
+    comm = _StreamOrderedComm(shards)
+    r0 = TileParallelRenderer(scene, camera, depth=depth, rank=0, world=world, gather_fn=comm.gather,
+                              frames_in_flight=in_flight)
+    assert r0.frames_in_flight == in_flight and len(r0._comm["render"]) == in_flight
+    got = []
+    for k, pos in enumerate(poses):          # pass 2: queued back to back
+        apply(k)
+        camera.position = vec3(pos)
+        r0.render_frame()
+        got.append(r0.framebuffer.clone())   # ordered behind this frame's untile on the caller's stream
+    r0.finish()
+    torch.cuda.synchronize()
+    for k in range(len(poses)):
+        assert torch.equal(got[k], want[k]), f"frame {k} with {in_flight} frames in flight"
+    assert torch.equal(r0.framebuffer, want[-1])
 
 
 def test_frame_graph_replays_with_new_poses():

@@ -68,18 +68,22 @@ class OracleBackend:
             image[i0:i0 + w, j0:j0 + h] = gathered[t % world, t // world, :w, :h]
 
 
-def _worker(rank, world, port, frames, q):
+def _worker(rank, world, port, frames, q, in_flight=2):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         image = _oracle_image()
         from rtgs.parallel import TileParallelRenderer, local_tile_count, tiles_of
-        r = TileParallelRenderer(backend=OracleBackend(image), rank=rank, world=world)
+        r = TileParallelRenderer(backend=OracleBackend(image), rank=rank, world=world, frames_in_flight=in_flight)
+        assert r.frames_in_flight == in_flight and len(r.compact) == max(in_flight, 2)
         assert r.total_tiles == tiles_of(W, H, TILE) == 9
         assert r.local_tiles == local_tile_count(9, rank, world)
-        for _ in range(frames):
+        for k in range(frames):
             r.render_frame()
+            # at most F frames are outstanding after a call (F - 1 once the oldest has been completed)
+            assert len(r._pending) == min(k + 1, max(in_flight, 2) - 1)
         r.finish()
+        assert not r._pending
         if rank == 0:
             q.put(float((r.framebuffer - image * float(frames)).abs().max()))
     finally:
@@ -92,11 +96,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,frames", [(2, 1), (2, 4), (3, 3)])
-def test_sharded_frames_reassemble_on_rank0(world, frames):
+@pytest.mark.parametrize("world,frames,in_flight", [(2, 1, 2), (2, 4, 2), (3, 3, 2), (2, 7, 3), (3, 5, 3), (2, 2, 1)])
+def test_sharded_frames_reassemble_on_rank0(world, frames, in_flight):
+    # every frame differs (OracleBackend scales by the frame number): the framebuffer must hold the
+    # LAST one whatever the ring position it ends on, with 1, 2 and 3 frames in flight
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    mp.spawn(_worker, args=(world, _free_port(), frames, q), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), frames, q, in_flight), nprocs=world, join=True)
     assert q.get(timeout=30) == 0.0
 
 
