@@ -348,7 +348,7 @@ def main():
         comm = ""
         if world > 1:
             comm = " + RCCL gather" if args.backend == "nccl" else f" + {args.backend} gather (rehearsal, not RCCL)"
-            comm += f", {renderer.frames_in_flight} frames in flight per rank"
+            comm += f", {renderer.frames_in_flight} frames in flight per rank, {renderer.gather_batch} per gather"
         line = {
             "metric": metric,
             "value": mrays, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RTGS_ABI_VERSION 4
+#define RTGS_ABI_VERSION 5
 #define RTGS_MAX_DEPTH 16        /* peels kept per ray in one pass (__main__.py:70 default) */
 #ifndef RTGS_TILE
 #define RTGS_TILE 16             /* macro-tile edge in pixels: one workgroup, the unit of sharding */
@@ -203,6 +203,32 @@ int rtgs_render(const RtgsScene* scene, const RtgsCamera* cam, int32_t depth, fl
  * by RTGS_TRACE_COMPACT with (tile_first, tile_step) = (rank, world)) into image [W][H][3]. */
 int rtgs_untile(const float* compact, int32_t world, int32_t tiles_per_rank, int32_t width,
                 int32_t height, float* image, rtgs_stream_t stream);
+
+/* ---- stream plumbing of the tile-parallel frame loop (rtgs.parallel.TileParallelRenderer) ----
+ * The reference has no multi-device path; these keep the per-frame HOST cost of the
+ * loop at two library calls + the collective.  Events are hipEvent_t (timing disabled) behind void*.
+ * rtgs_event_query: 1 = complete or never recorded, 0 = pending. */
+int rtgs_event_create(void** event);
+int rtgs_event_destroy(void* event);
+int rtgs_event_query(void* event);
+
+/* One shard of one frame, render side: [render_stream waits for reuse_event unless it is complete
+ * or NULL -- the previous reader of `out`] -> rtgs_project + rtgs_trace of the shard on render_stream
+ * (as rtgs_trace with projected = 0, ray_start_stride 1; attenuation_buf / ray_start only needed for
+ * depth > RTGS_MAX_DEPTH) -> traced_event recorded on render_stream -> [consumer_stream made to wait
+ * for it when consumer_waits != 0; it is an argument of its own because the NULL stream is a stream]. */
+int rtgs_shard_frame(const RtgsScene* scene, const RtgsCamera* cam, const RtgsTraceParams* params,
+                     float* out, float* attenuation_buf, float* ray_start, void* workspace, size_t workspace_bytes,
+                     rtgs_stream_t render_stream, void* reuse_event, void* traced_event,
+                     rtgs_stream_t consumer_stream, int32_t consumer_waits);
+
+/* Destination side, after the gather was queued on `stream`: records sent_event there (the senders'
+ * buffers may be reused once it completes; may be NULL), then scatters the first n_land of `batch`
+ * frames -- gathered[rank][frame][local_tile][T][T][3], every rank's block holding `batch` frames'
+ * shards -- into images[0 .. n_land) (HOST array of device pointers, [W][H][3] each).  batch = 1 is
+ * rtgs_untile.  n_land = 0 (ranks that are not the destination): only the event. */
+int rtgs_frames_land(const float* gathered, int32_t world, int32_t tiles_per_rank, int32_t batch, int32_t n_land,
+                     int32_t width, int32_t height, float* const* images, rtgs_stream_t stream, void* sent_event);
 
 /* Scene.hit (scene.py:406-450) for a batch of arbitrary rays: brute-force closest hit,
  * argmin t1 subject to ray.start < t1 < ray.end; lowest index wins exact ties.

@@ -1617,15 +1617,17 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   }
 }
 
+// rank_stride: tiles between consecutive ranks' blocks (tiles_per_rank for one frame per gather,
+// batch x tiles_per_rank when every rank sends `batch` frames' shards in one block)
 __global__ __launch_bounds__(256) void k_untile(const float* __restrict__ compact, int world,
-                                                 int tiles_per_rank, int width, int height,
+                                                 int rank_stride, int width, int height,
                                                  int tiles_x, float* __restrict__ image) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= width * height) return;
   const int i = p / height, j = p % height;
   const int tile = (j / kTile) * tiles_x + i / kTile;
   const int rank = tile % world, local = tile / world;
-  const float* s = compact + (((size_t)rank * tiles_per_rank + local) * kTile * kTile +
+  const float* s = compact + (((size_t)rank * rank_stride + local) * kTile * kTile +
                               (size_t)(i % kTile) * kTile + (j % kTile)) * 3;
   float* o = image + (size_t)p * 3;
   o[0] = s[0]; o[1] = s[1]; o[2] = s[2];
@@ -1957,6 +1959,71 @@ int rtgs_render(const RtgsScene* scene, const RtgsCamera* cam, int32_t depth, fl
   p.tile_order = nullptr;
   return trace_impl(scene, cam, &p, sample_out, transmittance_out, nullptr, 1, workspace, workspace_bytes,
                     0, (tile_y1 - tile_y0) * tiles_x, stream);
+}
+
+// ---- the tile-parallel frame loop's stream plumbing, in ONE call per side -------------------------
+// (rtgs.parallel spent 40 us of host time per frame on five torch / ctypes calls around two launches)
+
+int rtgs_event_create(void** event) {
+  if (!event) return RTGS_EINVAL;
+  hipEvent_t e;
+  if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return RTGS_EDEVICE;
+  *event = e;
+  return RTGS_OK;
+}
+
+int rtgs_event_destroy(void* event) {
+  if (!event) return RTGS_EINVAL;
+  return hipEventDestroy(static_cast<hipEvent_t>(event)) == hipSuccess ? RTGS_OK : RTGS_EDEVICE;
+}
+
+int rtgs_event_query(void* event) {
+  if (!event) return RTGS_EINVAL;
+  const hipError_t e = hipEventQuery(static_cast<hipEvent_t>(event));
+  if (e == hipSuccess) return 1;
+  if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+  return RTGS_EDEVICE;
+}
+
+int rtgs_shard_frame(const RtgsScene* scene, const RtgsCamera* cam, const RtgsTraceParams* params,
+                     float* out, float* attenuation_buf, float* ray_start, void* workspace, size_t workspace_bytes,
+                     rtgs_stream_t render_stream, void* reuse_event, void* traced_event,
+                     rtgs_stream_t consumer_stream, int32_t consumer_waits) {
+  if (!traced_event) return RTGS_EINVAL;
+  hipStream_t rs = static_cast<hipStream_t>(render_stream);
+  // the buffer's previous reader: usually long done, and then the render stream is spared the barrier packet
+  if (reuse_event && hipEventQuery(static_cast<hipEvent_t>(reuse_event)) != hipSuccess) {
+    (void)hipGetLastError();
+    if (hipStreamWaitEvent(rs, static_cast<hipEvent_t>(reuse_event), 0) != hipSuccess) return RTGS_EDEVICE;
+  }
+  if (int rc = trace_impl(scene, cam, params, out, attenuation_buf, ray_start, 1, workspace, workspace_bytes, 0,
+                          INT32_MAX, render_stream))
+    return rc;
+  if (hipEventRecord(static_cast<hipEvent_t>(traced_event), rs) != hipSuccess) return RTGS_EDEVICE;
+  if (consumer_waits &&
+      hipStreamWaitEvent(static_cast<hipStream_t>(consumer_stream), static_cast<hipEvent_t>(traced_event), 0) != hipSuccess)
+    return RTGS_EDEVICE;
+  return RTGS_OK;
+}
+
+int rtgs_frames_land(const float* gathered, int32_t world, int32_t tiles_per_rank, int32_t batch, int32_t n_land,
+                     int32_t width, int32_t height, float* const* images, rtgs_stream_t stream, void* sent_event) {
+  if (world <= 0 || tiles_per_rank <= 0 || batch <= 0 || n_land < 0 || n_land > batch || width <= 0 || height <= 0)
+    return RTGS_EINVAL;
+  if ((int64_t)world * tiles_per_rank < rtgs_num_tiles(width, height)) return RTGS_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // the gather queued before this call has read the senders' buffers: they may be traced into again
+  if (sent_event && hipEventRecord(static_cast<hipEvent_t>(sent_event), s) != hipSuccess) return RTGS_EDEVICE;
+  if (n_land == 0) return RTGS_OK;
+  if (!gathered || !images) return RTGS_EINVAL;
+  const int npx = width * height, block = 256;
+  for (int32_t b = 0; b < n_land; ++b) {
+    if (!images[b]) return RTGS_EINVAL;
+    hipLaunchKernelGGL(k_untile, dim3((npx + block - 1) / block), dim3(block), 0, s,
+                       gathered + (size_t)b * tiles_per_rank * kTile * kTile * 3, world, batch * tiles_per_rank,
+                       width, height, (width + kTile - 1) / kTile, images[b]);
+  }
+  return check_launch();
 }
 
 #if RTGS_COUNT

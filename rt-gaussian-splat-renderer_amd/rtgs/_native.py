@@ -14,7 +14,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_size_t, c_u
 
 import torch  # noqa: F401  (must precede the CDLL load, see module docstring)
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_DEPTH = 16
 RAY_FLOATS = 8
 SH_COEFFS = 15
@@ -65,6 +65,14 @@ PROTOTYPES = {
     "rtgs_project_shard": (c_int32, [POINTER(RtgsScene), POINTER(RtgsCamera), c_int32, c_int32, c_void_p,
                                      c_size_t, c_void_p]),
     "rtgs_untile": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "rtgs_event_create": (c_int32, [POINTER(c_void_p)]),
+    "rtgs_event_destroy": (c_int32, [c_void_p]),
+    "rtgs_event_query": (c_int32, [c_void_p]),
+    "rtgs_shard_frame": (c_int32, [POINTER(RtgsScene), POINTER(RtgsCamera), POINTER(RtgsTraceParams), c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_int32]),
+    "rtgs_frames_land": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p,
+                                   c_void_p, c_void_p]),
     "rtgs_closest_hit": (c_int32, [POINTER(RtgsScene), c_int32, c_void_p, c_void_p, c_void_p,
                                    c_void_p]),
     "rtgs_accel_bytes": (c_size_t, [c_int32]),

@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import os
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -78,6 +79,7 @@ class HipBackend:
         self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
         self._orders = {}
         self._state = {}
+        self._scene_native = self._camera_native = None
         # Optional hipGraph replay of project + trace (RTGS_GRAPH=1).  OFF by default: measured on
         # MI355X / ROCm 7.2 (tools/graph_vs_direct.py) a replay costs 12 us more per frame than the
         # two direct launches and holds the host until the graph has run (c3 1/8 shard: 70.9 vs
@@ -90,6 +92,21 @@ class HipBackend:
         # 0.1553 -> 0.1618 ms per frame, c5 1.345 -> 1.382 with the host queueing 200 frames ahead)
         self.pipeline = os.environ.get("RTGS_PIPELINE", "0") == "1"
         self._pipe = None
+
+    def scene_native(self):
+        """``scene.native()`` cached per commit (the struct only holds the streamed tensors' addresses)."""
+        sc = self.scene
+        if self._scene_native is None or self._scene_native[0] != sc.version:
+            self._scene_native = (sc.version, sc.native())
+        return self._scene_native[1]
+
+    def camera_native(self):
+        """``camera.native()`` cached per pose: the frame loop rebuilds it only when the camera moved."""
+        c = self.camera
+        key = (bytes(memoryview(c.position)), bytes(memoryview(c.rotation)), bytes(memoryview(c.focal_length)))
+        if self._camera_native is None or self._camera_native[0] != key:
+            self._camera_native = (key, c.native())
+        return self._camera_native[1]
 
     def tile_order(self, tile_first: int, tile_step: int):
         key = (tile_first, tile_step)
@@ -251,12 +268,20 @@ class TileParallelRenderer:
     With F frames in flight every rank alternates its frames over F render streams, each with its
     own workspace, so consecutive frames' traces overlap (two 1/8-shard traces: 43.5 us per pair
     against 74.3 one after the other, tools/concurrency_probe.py) and the loop is bound by
-    throughput, not by one tile's latency.  Each frame still costs its render stream exactly one
-    event record; the gather and the untile stay on the caller's stream, in frame order."""
+    throughput, not by one tile's latency.  Each frame costs its render stream exactly one event
+    record; the gather and the untile stay on the caller's stream, in frame order.  The render side
+    of a frame is ONE library call (``rtgs_shard_frame``: reuse wait, project, trace, event record,
+    consumer wait), the landing side another (``rtgs_frames_land``: event record + untile).
+
+    ``gather_batch`` (default 1, ``RTGS_GATHER_BATCH``): B consecutive frames' shards travel in one
+    collective (each rank sends [B][tiles][T][T][3]) and land in a ring of B framebuffers, the
+    newest being ``framebuffer``: the collective's fixed host and launch cost (16-26 us per call,
+    more than a 1/8-shard trace of a 1080p frame) is paid once per B frames, at the price of B - 1
+    frames of latency.  ``finish()`` flushes a partial batch."""
 
     def __init__(self, scene=None, camera=None, depth: int = 16, rank: int = 0, world: int = 1,
                  t_cutoff: float = 0.0, dst: int = 0, group=None, backend=None, gather_fn=None,
-                 frames_in_flight: int | None = None):
+                 frames_in_flight: int | None = None, gather_batch: int | None = None):
         self.backend = backend if backend is not None else HipBackend(scene, camera, depth, t_cutoff)
         self._gather = gather_fn if gather_fn is not None else dist.gather   # injectable for tests
         self.rank, self.world, self.dst, self.group = int(rank), int(world), int(dst), group
@@ -265,42 +290,88 @@ class TileParallelRenderer:
         self.total_tiles = tiles_of(b.width, b.height, self.TILE)
         self.tiles_per_rank = (self.total_tiles + self.world - 1) // self.world
         self.local_tiles = local_tile_count(self.total_tiles, self.rank, self.world)
-        self.framebuffer = b.alloc(b.width, b.height, 3) if (self.world == 1 or self.rank == self.dst) else None
         if frames_in_flight is None:
             frames_in_flight = int(os.environ.get("RTGS_FRAMES_IN_FLIGHT", "2"))
-        if frames_in_flight < 1:
-            raise ValueError("frames_in_flight must be >= 1")
+        if gather_batch is None:
+            gather_batch = int(os.environ.get("RTGS_GATHER_BATCH", "1"))
+        if frames_in_flight < 1 or gather_batch < 1:
+            raise ValueError("frames_in_flight and gather_batch must be >= 1")
+        streams = (self.world > 1 and isinstance(b, HipBackend) and
+                   os.environ.get("RTGS_RENDER_STREAM", "1") != "0")
         self.frames_in_flight = int(frames_in_flight) if self.world > 1 else 1
+        self.gather_batch = int(gather_batch) if streams else 1
+        is_dst = self.world == 1 or self.rank == self.dst
+        self._fbs = [b.alloc(b.width, b.height, 3) for _ in range(self.gather_batch)] if is_dst else []
+        self._landed = 0            # which of _fbs holds the newest frame
         self._pending = []          # one-stream form: (work, slot) of the gathers not yet completed
         self._frame = 0
         self._comm = None
         if self.world > 1:
-            F = self.frames_in_flight
-            streams = isinstance(b, HipBackend) and os.environ.get("RTGS_RENDER_STREAM", "1") != "0"
-            # buffer ring.  Two-stream form: 2 F slots, so that a render stream never waits for the
-            # gather of the frame it traced last (only for the one before that, long done);
-            # one-stream form: at most F gathers are outstanding, F slots
-            self._slots = 2 * F if streams else max(F, 2)
+            F, B = self.frames_in_flight, self.gather_batch
             shard = (self.tiles_per_rank, self.TILE, self.TILE, 3)
-            self.compact = [b.alloc(*shard) for _ in range(self._slots)]
-            n_g = (2 if streams else self._slots) if self.rank == self.dst else 0
-            # (two-stream form: gather and untile of consecutive frames are serial on the caller's
-            # stream, two landing buffers are plenty; one-stream form: one per outstanding gather)
-            self.gathered = [b.alloc(self.world, *shard) for _ in range(n_g)]
+            if streams:
+                # batch-slot ring: deep enough that a render stream never waits for the gather of the
+                # batch it traced into last (only for one S batches back, long done)
+                self._slots = (2 * F + B - 1) // B + 1
+                self.compact = [b.alloc(B, *shard) for _ in range(self._slots)]
+                # gather and landing of consecutive batches are serial on the caller's stream: two
+                # landing buffers are plenty
+                self.gathered = [b.alloc(self.world, B, *shard) for _ in range(2)] if is_dst else []
+            else:
+                # one-stream form: at most F gathers outstanding, one slot and landing buffer each
+                self._slots = max(F, 2)
+                self.compact = [b.alloc(*shard) for _ in range(self._slots)]
+                self.gathered = [b.alloc(self.world, *shard) for _ in range(self._slots)] if is_dst else []
             # the per-rank views torch.distributed.gather wants, made once (8 views cost ~8 us per frame)
             self._glist = [list(g.unbind(0)) for g in self.gathered]
             if streams:
-                # F + 1 streams: the shards are rendered on streams of their own (handed to the C ABI
-                # as an argument, never made current), the gather and the untile stay on the caller's
-                # stream.  Neither side waits for the other's current frame -- only for the buffer it
-                # is about to reuse -- and the collective can be issued in its blocking form, which
-                # costs the host 16 us instead of the 28 us of async_op=True + wait()
-                # (tools/host_overhead.py)
-                self._comm = dict(render=[torch.cuda.Stream(device=b.device) for _ in range(F)],
-                                  ws=[b.workspace] + [torch.empty_like(b.workspace) for _ in range(F - 1)],
-                                  traced=[torch.cuda.Event() for _ in range(self._slots)],
-                                  sent=[torch.cuda.Event() for _ in range(self._slots)],
-                                  seen=[None] * F)
+                self._comm = self._make_stream_state(F, B)
+
+    @property
+    def framebuffer(self):
+        """(W, H, 3) image of the newest frame that has landed (rank dst; None elsewhere)."""
+        return self._fbs[self._landed] if self._fbs else None
+
+    def _make_stream_state(self, F: int, B: int):
+        """F render streams (handed to the C ABI as arguments, never made current) with a workspace
+        each; per frame slot a `traced` event, per batch slot a `sent` event (raw hipEvent_t handles:
+        the library records and waits on them inside rtgs_shard_frame / rtgs_frames_land)."""
+        import ctypes
+        b = self.backend
+        nat = b.nat
+        lib = nat.lib()
+
+        def event():
+            h = ctypes.c_void_p()
+            nat.check(lib.rtgs_event_create(ctypes.byref(h)), "rtgs_event_create")
+            return h.value
+
+        order = b.tile_order(self.rank, self.world) if (b.use_tile_order and self.local_tiles) else None
+        params = nat.RtgsTraceParams(b.depth, b.t_cutoff, self.rank, self.world, nat.TRACE_COMPACT, nat.ptr(order))
+        ws = [b.workspace] + [torch.empty_like(b.workspace) for _ in range(F - 1)]
+        state = [(None, None)] * F
+        if b.depth > nat.MAX_DEPTH:      # chained launches need per-pixel state, one pair per frame in flight
+            state = [(b.alloc(b.width, b.height), b.alloc(b.width, b.height)) for _ in range(F)]
+        images = (ctypes.c_void_p * B)(*[fb.data_ptr() for fb in self._fbs]) if self._fbs else None
+        return dict(render=[torch.cuda.Stream(device=b.device) for _ in range(F)], ws=ws, state=state,
+                    traced=[[event() for _ in range(B)] for _ in range(self._slots)],
+                    sent=[event() for _ in range(self._slots)], seen=[None] * F,
+                    params=params, order=order, images=images, g=0, lib=lib)
+
+    def close(self) -> None:
+        """Drain the render streams and release the events (also runs when the object is collected)."""
+        cm, self._comm = self._comm, None
+        if cm is not None:
+            for rs in cm["render"]:
+                rs.synchronize()
+            for ev in [e for row in cm["traced"] for e in row] + cm["sent"]:
+                cm["lib"].rtgs_event_destroy(ev)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     # ---- frame loop ------------------------------------------------------------------------
     def _scene_key(self):
@@ -313,45 +384,43 @@ class TileParallelRenderer:
 
     def render_frame(self) -> None:
         """Queue one frame.  world == 1: straight into ``framebuffer``.  world > 1: trace this
-        rank's tiles into a slot of the compact-buffer ring on render stream f mod F, gather them
-        (and, on rank dst, untile) on the caller's stream while the render streams go on with the
-        next frames: ``framebuffer`` is complete in the caller's stream order.  (Without a HIP
-        backend -- the CPU tests' stand-in -- or with RTGS_RENDER_STREAM=0: one stream; start the
-        gather, then complete the oldest outstanding frame once F are in flight.)"""
+        rank's tiles into a slot of the compact-buffer ring on render stream f mod F; once the B
+        frames of a batch are queued, gather them (and, on rank dst, untile) on the caller's stream
+        while the render streams go on with the next frames: ``framebuffer`` is complete in the
+        caller's stream order.  (Without a HIP backend -- the CPU tests' stand-in -- or with
+        RTGS_RENDER_STREAM=0: one stream; start the gather, then complete the oldest outstanding
+        frame once F are in flight.)"""
         b = self.backend
         if self.world == 1:
-            b.render(self.framebuffer, 0, 1, compact=False)
+            b.render(self._fbs[0], 0, 1, compact=False)
             return
         f = self._frame
         self._frame += 1
-        k = f % self._slots
         if self._comm is not None:
-            cm = self._comm
+            cm, nat = self._comm, b.nat
+            B = self.gather_batch
+            q, j = divmod(f, B)
+            slot = q % self._slots
             s = f % self.frames_in_flight
             rs = cm["render"][s]
-            cur = b.nat.current_stream(b.device.index)    # the caller's stream
             key = self._scene_key()
             if cm["seen"][s] != key:
-                rs.wait_stream(cur)                # scene uploads / edits queued on the caller's stream
+                # scene uploads / edits queued on the caller's stream (rare: torch objects are fine here)
+                rs.wait_stream(nat.current_stream(b.device.index))
                 cm["seen"][s] = key
-            # the gather 2 F frames back has read compact[k].  (Guarding the reuse from the host
-            # instead -- event.synchronize() on a ring of 2 or 4 buffers -- keeps this barrier packet
-            # off the render stream but blocks a host that runs ahead, every frame: 79 / 73 us per
-            # frame against 67.)
-            if not cm["sent"][k].query():          # usually long done: then the render stream is spared the packet
-                rs.wait_event(cm["sent"][k])
-            if self.local_tiles:
-                b.render(self.compact[k], self.rank, self.world, compact=True, stream=rs, workspace=cm["ws"][s])
-            cm["traced"][k].record(rs)
-            cur.wait_event(cm["traced"][k])        # gather this frame's shard once it is traced
-            g = f & 1
-            self._gather(self.compact[k], gather_list=self._glist[g] if self._glist else None, dst=self.dst,
-                         group=self.group, async_op=False)
-            cm["sent"][k].record(cur)
-            if self.rank == self.dst:
-                b.untile(self.gathered[g], self.world, self.tiles_per_rank, self.framebuffer,
-                         stream=cur)
+            cur = nat.stream()                     # raw handle of the caller's stream
+            ws = cm["ws"][s]
+            att, start = cm["state"][s]
+            out = self.compact[slot]
+            nat.check(cm["lib"].rtgs_shard_frame(
+                b.scene_native(), b.camera_native(), cm["params"],
+                out.data_ptr() + j * out.stride(0) * 4, nat.ptr(att), nat.ptr(start),
+                ws.data_ptr(), ws.numel(), rs.cuda_stream, cm["sent"][slot], cm["traced"][slot][j], cur, 1),
+                "rtgs_shard_frame")
+            if j == B - 1:
+                self._exchange(slot, B, cur)
             return
+        k = f % self._slots
         if self.local_tiles:
             b.render(self.compact[k], self.rank, self.world, compact=True)
         work = self._gather(self.compact[k], gather_list=self._glist[k] if self._glist else None, dst=self.dst,
@@ -360,20 +429,41 @@ class TileParallelRenderer:
         while len(self._pending) >= max(self.frames_in_flight, 2):
             self._complete(self._pending.pop(0))
 
+    def _exchange(self, slot: int, n_frames: int, cur: int) -> None:
+        """Gather batch slot `slot` on the caller's stream (it already waits for the batch's traces)
+        and land its first n_frames frames."""
+        cm, b = self._comm, self.backend
+        g = cm["g"]
+        cm["g"] = g ^ 1
+        self._gather(self.compact[slot], gather_list=self._glist[g] if self._glist else None, dst=self.dst,
+                     group=self.group, async_op=False)
+        land = n_frames if self._fbs else 0
+        b.nat.check(cm["lib"].rtgs_frames_land(
+            self.gathered[g].data_ptr() if self.gathered else None, self.world, self.tiles_per_rank,
+            self.gather_batch, land, b.width, b.height, cm["images"], cur, cm["sent"][slot]), "rtgs_frames_land")
+        if land:
+            self._landed = land - 1
+
     def _complete(self, pending) -> None:
         work, k = pending
         work.wait()
-        if self.rank == self.dst:
-            self.backend.untile(self.gathered[k], self.world, self.tiles_per_rank, self.framebuffer)
+        if self._fbs:
+            self.backend.untile(self.gathered[k], self.world, self.tiles_per_rank, self._fbs[0])
 
     def finish(self) -> None:
         """Drain the pipeline: after this ``framebuffer`` on rank dst holds the last frame (in the
         caller's stream order) and the render streams have nothing queued that the caller's stream
-        has not waited for -- buffers may be released, the scene re-committed."""
+        has not waited for -- buffers may be released, the scene re-committed.  A partial batch is
+        exchanged as it is (every rank calls finish() after the same number of frames)."""
         while self._pending:
             self._complete(self._pending.pop(0))
         if self._comm is not None:
-            cur = self.backend.nat.current_stream(self.backend.device.index)
+            b, B = self.backend, self.gather_batch
+            q, j = divmod(self._frame, B)
+            if j:
+                self._exchange(q % self._slots, j, b.nat.stream())
+                self._frame = (q + 1) * B          # the next frame opens a new batch
+            cur = b.nat.current_stream(b.device.index)
             for rs in self._comm["render"]:
                 cur.wait_stream(rs)
 

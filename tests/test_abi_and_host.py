@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
 def test_pure_host_entry_points():
     from rtgs import _native as nat
     lib = nat.lib()
-    assert lib.rtgs_abi_version() == nat.ABI_VERSION == 4
+    assert lib.rtgs_abi_version() == nat.ABI_VERSION == 5
     assert lib.rtgs_strerror(0) == b"ok"
     for code in (-1, -2, -3, -4, -5, -99):
         assert len(lib.rtgs_strerror(code)) > 0
@@ -68,6 +68,10 @@ def test_argument_validation_needs_no_gpu():
     assert lib.rtgs_fill(None, 4, 0.0, None) == -1
     assert lib.rtgs_quat_op(7, 1, None, None, None, None) == -1
     assert lib.rtgs_untile(None, 1, 1, 4, 4, None, None) == -1
+    assert lib.rtgs_event_create(None) == -1 and lib.rtgs_event_destroy(None) == -1 and lib.rtgs_event_query(None) == -1
+    assert lib.rtgs_shard_frame(None, None, None, None, None, None, None, 0, None, None, None, None, 0) == -1
+    assert lib.rtgs_frames_land(None, 0, 1, 1, 0, 4, 4, None, None, None) == -1
+    assert lib.rtgs_frames_land(None, 1, 1, 2, 3, 4, 4, None, None, None) == -1       # n_land > batch
     cam = nat.make_camera((0, 0, 0), (0, 0, 0, 1), 64, 64, 64.0, 64.0)
     assert lib.rtgs_trace(None, cam, None, None, None, None, 1, None, 0, 0, None) == -1
     with pytest.raises(ValueError):

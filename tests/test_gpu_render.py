@@ -764,18 +764,23 @@ class _StreamOrderedComm:
     stream -- no device-wide synchronize that would paper over a missing event: the other ranks'
     shards of every frame were rendered beforehand."""
 
-    def __init__(self, shards):
-        self.shards, self.frame = shards, 0
+    def __init__(self, shards, batch=1):
+        self.shards, self.frame, self.batch = shards, 0, batch
 
     def gather(self, tensor, gather_list=None, dst=0, group=None, async_op=False):
-        for r, out in enumerate(gather_list):
-            out.copy_(tensor if r == 0 else self.shards[self.frame][r], non_blocking=True)
-        self.frame += 1
+        n = min(self.batch, len(self.shards) - self.frame)       # a flushed partial batch holds fewer
+        for r, out in enumerate(gather_list):                    # out: [batch][tiles][T][T][3]
+            if r == 0:
+                out.copy_(tensor, non_blocking=True)
+            else:
+                for j in range(n):
+                    out[j].copy_(self.shards[self.frame + j][r], non_blocking=True)
+        self.frame += n
         return _FakeWork()
 
 
-@pytest.mark.parametrize("in_flight", [1, 2, 3])
-def test_frames_in_flight_keep_stream_order_without_host_syncs(in_flight):
+@pytest.mark.parametrize("in_flight,batch", [(1, 1), (2, 1), (3, 1), (2, 2), (3, 2), (4, 3)])
+def test_frames_in_flight_keep_stream_order_without_host_syncs(in_flight, batch):
     # VERDICT r2 #1 / ADVICE r2: F frames in flight per rank on F render streams + the caller's
     # stream.  Seven frames with seven poses and two in-place scene edits queued on the caller's
     # stream, NO host synchronisation in between; every frame's framebuffer (snapshotted in stream
@@ -808,21 +813,27 @@ def test_frames_in_flight_keep_stream_order_without_host_syncs(in_flight):
         shards.append(row)
     torch.cuda.synchronize()
     assert not torch.equal(want[2], want[3]) and not torch.equal(want[4], want[5])
-    comm = _StreamOrderedComm(shards)
+    comm = _StreamOrderedComm(shards, batch)
     r0 = TileParallelRenderer(scene, camera, depth=depth, rank=0, world=world, gather_fn=comm.gather,
-                              frames_in_flight=in_flight)
-    assert r0.frames_in_flight == in_flight and len(r0._comm["render"]) == in_flight
-    got = []
+                              frames_in_flight=in_flight, gather_batch=batch)
+    assert r0.frames_in_flight == in_flight and len(r0._comm["render"]) == in_flight and r0.gather_batch == batch
+    got = {}
     for k, pos in enumerate(poses):          # pass 2: queued back to back
         apply(k)
         camera.position = vec3(pos)
         r0.render_frame()
-        got.append(r0.framebuffer.clone())   # ordered behind this frame's untile on the caller's stream
-    r0.finish()
+        if (k + 1) % batch == 0:             # a batch has landed: snapshot its frames, ordered behind
+            for j in range(batch):           # their untile on the caller's stream
+                got[k + 1 - batch + j] = r0._fbs[j].clone()
+            assert r0.framebuffer is r0._fbs[batch - 1]
+    r0.finish()                              # flushes the partial last batch (7 frames)
+    for j in range(len(poses) % batch):
+        got[len(poses) - len(poses) % batch + j] = r0._fbs[j].clone()
     torch.cuda.synchronize()
     for k in range(len(poses)):
-        assert torch.equal(got[k], want[k]), f"frame {k} with {in_flight} frames in flight"
+        assert torch.equal(got[k], want[k]), f"frame {k} with {in_flight} frames in flight, {batch} per gather"
     assert torch.equal(r0.framebuffer, want[-1])
+    r0.close()
 
 
 def test_frame_graph_replays_with_new_poses():

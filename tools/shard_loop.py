@@ -39,12 +39,13 @@ for name in (sys.argv[1:] or ["c3", "c5"]):
     scene = rtgs.Scene.from_arrays(**arrays)
     camera = rtgs.Camera(cam["position"], cam["rotation"], (cfg.width, cfg.height), (cam["fx"], cam["fy"]))
     n = 400 if name != "c5" else 150
-    for F in (1, 2, 3, 4):
+    for F, B in ((1, 1), (2, 1), (3, 1), (2, 2), (4, 2), (3, 3), (4, 4)):
         for label, g in (("one-peer RCCL gather", gather1), ("no gather", nogather)):
-            r = TileParallelRenderer(scene, camera, depth=cfg.depth, rank=0, world=world, gather_fn=g, frames_in_flight=F)
+            r = TileParallelRenderer(scene, camera, depth=cfg.depth, rank=0, world=world, gather_fn=g,
+                                     frames_in_flight=F, gather_batch=B)
             host, total = timeit(r.render_frame, n)
             r.finish(); torch.cuda.synchronize()
-            print(f"{name} rank 0 of {world}, {F} frame(s) in flight, {label}: host {host:.1f} us, total {total:.1f} us per frame")
-            del r
+            print(f"{name} rank 0 of {world}, {F} frame(s) in flight, {B} per gather, {label}: host {host:.1f} us, total {total:.1f} us per frame")
+            r.close()
     del scene
 dist.destroy_process_group()
