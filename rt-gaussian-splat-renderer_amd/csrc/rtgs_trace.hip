@@ -63,6 +63,9 @@ namespace {
 #ifndef RTGS_COUNT
 #define RTGS_COUNT 0      // counting build (librtgs_hip_count.so, bench.py's honesty columns): every wave adds its
 #endif                    // candidate / hit / insertion counts to device counters read by rtgs_debug_counters()
+#ifndef RTGS_ABLATE_PAYLOAD
+#define RTGS_ABLATE_PAYLOAD 0
+#endif
 #ifndef RTGS_ABLATE
 #define RTGS_ABLATE 0     // timing-only builds (wrong images): 1 no insertion, 2 no hit path,
 #endif                    // 3 no per-candidate loop, 4 no slab expansion either
@@ -190,6 +193,13 @@ constexpr int kSuper = RTGS_SUPER;
 #endif
 
 constexpr int kBinSupertilesMax = 4096;   // supertile bins the workspace provides for (4 K at 64 px: 2 040), see k_bin
+#ifndef RTGS_TILE_BINS
+#define RTGS_TILE_BINS 1   // k_bin also writes every MACRO-TILE's own depth-sorted slab list (one load instead of the bin filter)
+#endif
+// per-macro-tile slab lists (k_bin): [count][ids ...], kTileBinCap ints = 1 KB per tile; a tile that lists more
+// slabs gets count -1 and filters its supertile's bin; frames of more than kTileBinTilesMax tiles have none
+constexpr int kTileBinCap = 256;
+constexpr int kTileBinTilesMax = 65536;
 constexpr int32_t kMaxGaussians = 1 << 26;   // 67 M: a record's byte offset (64 B each) fits 32 bits
 
 struct TraceArgs {
@@ -213,6 +223,7 @@ struct TraceArgs {
   const int32_t* bin_count;   // [supertiles], -1 = overflowed: that supertile's tiles scan for themselves
   const int32_t* bin_list;    // [supertiles][bin_stride]
   int32_t bin_stride, bin_shift, bin_sx;
+  const int32_t* tile_bin;    // [tiles][kTileBinCap] or NULL: per-macro-tile lists, valid where the supertile's bin is
 };
 
 #if RTGS_COUNT
@@ -525,9 +536,12 @@ __global__ __launch_bounds__(256) void k_bin(int32_t nslabs, const float4* __res
                                               const float4* __restrict__ super_bbox,
                                               const float* __restrict__ slab_key, int32_t width, int32_t height,
                                               int32_t shift, int32_t bin_sx, int32_t stride,
-                                              int32_t* __restrict__ bin_count, int32_t* __restrict__ bin_list) {
+                                              int32_t* __restrict__ bin_count, int32_t* __restrict__ bin_list,
+                                              int32_t* __restrict__ tile_bin, int32_t tiles_x, int32_t tiles_y) {
   __shared__ int s_id[kBinCapMax];
   __shared__ float s_key[kBinCapMax];
+  __shared__ float4 s_bb[RTGS_TILE_BINS ? kBinCapMax : 1];      // bounds of the listed slabs, then in sorted order
+  __shared__ int s_sid[RTGS_TILE_BINS ? kBinCapMax : 1];         // sorted ids
   __shared__ int s_wc[2][4];
   constexpr int kGrpCap = RTGS_BIN_GROUPS;
   __shared__ int s_grp[kGroups ? kGrpCap : 1];
@@ -619,6 +633,7 @@ __global__ __launch_bounds__(256) void k_bin(int32_t nslabs, const float4* __res
         const int at = off + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(km[it] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km[it], 0u));
         s_id[at] = sid[it];
         s_key[at] = sk[it];
+        if constexpr (RTGS_TILE_BINS != 0) s_bb[at] = sb[it];
       }
       off += __popcll(km[it]);
     }
@@ -629,16 +644,61 @@ __global__ __launch_bounds__(256) void k_bin(int32_t nslabs, const float4* __res
   }
   __syncthreads();
   // nearest first: rank by (key, slab id) -- the ids were listed in increasing order
-  for (int e = tid; e < cnt; e += 256) {
-    const float my = s_key[e];
-    int rank = 0;
-    for (int j = 0; j < cnt; ++j) {
-      const float kj = s_key[j];
-      rank += (kj < my || (kj == my && j < e)) ? 1 : 0;
+  constexpr int kPer = kBinCapMax / 256;
+  int rank[kPer];
+  float4 mybb[kPer];
+#pragma unroll
+  for (int q = 0; q < kPer; ++q) {
+    const int e = tid + q * 256;
+    rank[q] = -1;
+    if (e < cnt) {
+      const float my = s_key[e];
+      int r = 0;
+      for (int j = 0; j < cnt; ++j) {
+        const float kj = s_key[j];
+        r += (kj < my || (kj == my && j < e)) ? 1 : 0;
+      }
+      rank[q] = r;
+      bin_list[(size_t)st * stride + r] = s_id[e];
+      if constexpr (RTGS_TILE_BINS != 0) mybb[q] = s_bb[e];
     }
-    bin_list[(size_t)st * stride + rank] = s_id[e];
   }
   if (tid == 0) bin_count[st] = cnt;
+  if constexpr (RTGS_TILE_BINS != 0) {
+    if (!tile_bin) return;
+    // The macro-tiles' own lists: the sorted list filtered by each tile's bounds, order preserved (= what
+    // the tile's filter of this bin would keep).  One wave per tile, 64 listed slabs per step.
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kPer; ++q)
+      if (rank[q] >= 0) { s_bb[rank[q]] = mybb[q]; s_sid[rank[q]] = s_id[tid + q * 256]; }
+    __syncthreads();
+    const int per_edge = 1 << shift, ntl = per_edge * per_edge;
+    for (int t = wave; t < ntl; t += 4) {
+      const int tx = (st % bin_sx) * per_edge + (t % per_edge), ty = (st / bin_sx) * per_edge + (t / per_edge);
+      if (tx >= tiles_x || ty >= tiles_y) continue;
+      const int mi0 = tx * kTile, mj0 = ty * kTile;
+      const float tXlo = ((float)mi0 + 0.5f) - hw, tXhi = ((float)min(mi0 + kTile, width) - 0.5f) - hw;
+      const float tYlo = ((float)mj0 + 0.5f) - hh, tYhi = ((float)min(mj0 + kTile, height) - 0.5f) - hh;
+      int32_t* const out = tile_bin + (size_t)(ty * tiles_x + tx) * kTileBinCap;
+      int n = 0;
+      for (int base = 0; base < cnt; base += kWave) {
+        const int e = base + lane;
+        bool keep = false;
+        int id = 0;
+        if (e < cnt) {
+          const float4 b = s_bb[e];
+          id = s_sid[e];
+          keep = b.x <= tXhi && b.z >= tXlo && b.y <= tYhi && b.w >= tYlo;
+        }
+        const unsigned long long km2 = __ballot(keep);
+        const int at = n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(km2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km2, 0u));
+        if (keep && at < kTileBinCap - 1) out[1 + at] = id;
+        n += __popcll(km2);
+      }
+      if (lane == 0) out[0] = n <= kTileBinCap - 1 ? n : -1;
+    }
+  }
 }
 
 struct Rgb { float r, g, b; };
@@ -716,7 +776,11 @@ __device__ __forceinline__ void list_insert2(unsigned (&kt)[kK], unsigned (&kp)[
 #else
     kt[k] = lt[k - 1 - kB] ? kt[k - 1] : (lt[k - kB] ? tn : kt[k]);
 #endif
+#if RTGS_ABLATE_PAYLOAD   // (timing only -- one operation per payload slot instead of a compare and two selects)
+    kp[k] = min(kp[k] + 16u, pn);
+#else
     kp[k] = lt[k - 1 - kB] ? kp[k - 1] : (lt[k - kB] ? pn : kp[k]);
+#endif
   }
   if constexpr (kLo == 0) {
 #if RTGS_MED3
@@ -724,7 +788,11 @@ __device__ __forceinline__ void list_insert2(unsigned (&kt)[kK], unsigned (&kp)[
 #else
     kt[0] = lt[0] ? tn : kt[0];
 #endif
+#if RTGS_ABLATE_PAYLOAD
+    kp[0] = min(kp[0] + 16u, pn);
+#else
     kp[0] = lt[0] ? pn : kp[0];
+#endif
   }
 }
 
@@ -907,10 +975,21 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   const int bin_n = a.bin_count ? __builtin_amdgcn_readfirstlane(a.bin_count[bin_at]) : -1;
   const bool binned = bin_n >= 0;
   const int32_t* const bin = a.bin_list + (size_t)bin_at * a.bin_stride;
+  // this tile's own list (k_bin wrote it iff it wrote the supertile's bin): the count and every thread's entry
+  // are loaded together with bin_n above -- ONE round trip instead of bin count -> bin ids -> slab bounds
+  int tb_n = -1, tb_id = 0;
+  if constexpr (RTGS_TILE_BINS != 0) {
+    if (a.tile_bin) {
+      const int32_t* const tb = a.tile_bin + (size_t)tile * kTileBinCap;
+      tb_n = __builtin_amdgcn_readfirstlane(tb[0]);
+      if (tid < kTileBinCap - 1) tb_id = tb[1 + tid];
+    }
+  }
+  const bool tbinned = binned && tb_n >= 0;
   const int nsuper = (kTwo && !binned) ? (nslabs + kSuper - 1) / kSuper : 1;
   int par = 0;
   for (int ub = 0, upar = 0; ub < nsuper; ub += kSuperStep, upar ^= 1) {
-  int nitems = binned ? bin_n : nslabs;
+  int nitems = tbinned ? 0 : (binned ? bin_n : nslabs);
   if constexpr (kTwo) {
   if (!binned) {
     // ---- level 1: bounds of kSuper-slab groups; survivors in stream order into s_super ----
@@ -949,6 +1028,12 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   }
   const bool last_outer = ub + kSuperStep >= nsuper;
   for (int sbase = 0; sbase < nitems || (last_outer && sbase == 0); sbase += kSlabStep, par ^= 1) {
+    bool last = true;
+    if (tbinned) {
+      // the tile's list as k_bin wrote it: already filtered by this tile's bounds and nearest first
+      if (tid < tb_n) s_slab[tid] = (SlabId)tb_id;
+      scnt = tb_n;
+    } else {
     // ---- scan slab bounds; keep the slabs that touch the macro-tile.  The list is built
     // without atomics: every wave publishes its count, one barrier later every thread derives
     // the same offsets (s_wcnt is double-buffered by step parity).
@@ -995,8 +1080,9 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
       }
       off += __popcll(keep_m[it]);
     }
-    const bool last = last_outer && sbase + kSlabStep >= nitems;
+    last = last_outer && sbase + kSlabStep >= nitems;
     if (scnt + kSlabStep <= kSlabCap && !last) continue;
+    }
     __syncthreads();  // the slab list is complete
     if (!binned && kSortMax > 0 && scnt > 1 && scnt <= kSortMax) {   // (a bin is sorted already; filtering keeps the order)
       // nearest slabs first: rank by (key, list position), kSortPer listed slabs per thread (one for
@@ -1645,7 +1731,9 @@ extern "C" {
 // bins: [counts kBinSupertilesMax int][lists kBinSupertilesMax x bin_stride_of(nslabs) int], behind the depth keys
 static size_t bins_bytes(size_t nslabs) {
 #if RTGS_BINS
-  return (size_t)kBinSupertilesMax * sizeof(int32_t) * (1 + (size_t)bin_stride_of(nslabs));
+  // + the macro-tiles' own lists (64 MiB: 65 536 tiles x 1 KB -- an 8K x 4K frame; 2 % of it at 1080p)
+  return (size_t)kBinSupertilesMax * sizeof(int32_t) * (1 + (size_t)bin_stride_of(nslabs)) +
+         (RTGS_TILE_BINS ? (size_t)kTileBinTilesMax * kTileBinCap * sizeof(int32_t) : 0);
 #else
   (void)nslabs;
   return 0;
@@ -1760,6 +1848,13 @@ static int validate(const RtgsScene* scene, const RtgsCamera* cam, void* ws, siz
 
 }  // extern "C"
 
+// the macro-tiles' own slab lists live behind the supertile bins; frames of more tiles than the workspace provides
+// for (kTileBinTilesMax) have none
+static int32_t* tile_bin_of(int32_t* bin_count, size_t nslabs, int width, int height) {
+  if (!RTGS_TILE_BINS || rtgs_num_tiles(width, height) > kTileBinTilesMax) return nullptr;
+  return bin_count + (size_t)kBinSupertilesMax * (1 + (size_t)bin_stride_of(nslabs));
+}
+
 // want_bins: build the supertile bins (rtgs_project always asks; rtgs_trace's own projection only when
 // its shard is large enough for them to pay, see trace_impl)
 static int project_impl(const RtgsScene* scene, const RtgsCamera* cam, void* workspace,
@@ -1790,14 +1885,16 @@ static int project_impl(const RtgsScene* scene, const RtgsCamera* cam, void* wor
   if (bins) {
     const BinGeom g = bin_geom(cam->width, cam->height);
     float* keys = slab_key_of(slab_bbox, nn);
+    const int tiles_x = (cam->width + kTile - 1) / kTile, tiles_y = (cam->height + kTile - 1) / kTile;
+    int32_t* const tile_bin = tile_bin_of(bin_count, nslabs, cam->width, cam->height);
     if (groups)
       hipLaunchKernelGGL(k_bin<true>, dim3(g.supertiles), dim3(256), 0, static_cast<hipStream_t>(stream), nslabs,
                          slab_bbox, slab_bbox + nslabs, keys, cam->width, cam->height, g.shift, g.sx,
-                         bin_stride_of(nslabs), bin_count, bin_count + kBinSupertilesMax);
+                         bin_stride_of(nslabs), bin_count, bin_count + kBinSupertilesMax, tile_bin, tiles_x, tiles_y);
     else
       hipLaunchKernelGGL(k_bin<false>, dim3(g.supertiles), dim3(256), 0, static_cast<hipStream_t>(stream), nslabs,
                          slab_bbox, slab_bbox + nslabs, keys, cam->width, cam->height, g.shift, g.sx,
-                         bin_stride_of(nslabs), bin_count, bin_count + kBinSupertilesMax);
+                         bin_stride_of(nslabs), bin_count, bin_count + kBinSupertilesMax, tile_bin, tiles_x, tiles_y);
   }
   return check_launch();
 }
@@ -1875,7 +1972,7 @@ static int trace_impl(const RtgsScene* scene, const RtgsCamera* cam, const RtgsT
   a.inv_fy = (float)fc.inv_fy;
   for (int k = 0; k < 9; ++k) a.rc[k] = (float)fc.rc[k];
   a.pose = static_cast<const FrameCam*>(cam->device_pose);
-  a.bin_count = nullptr; a.bin_list = nullptr; a.bin_stride = 0; a.bin_shift = 0; a.bin_sx = 1;
+  a.bin_count = nullptr; a.bin_list = nullptr; a.bin_stride = 0; a.bin_shift = 0; a.bin_sx = 1; a.tile_bin = nullptr;
   if (use_bins((int)(nn / kSlab))) {
     const BinGeom g = bin_geom(cam->width, cam->height);
     const size_t nslabs_ = nn / kSlab, nsuper_ = (nslabs_ + kSuper - 1) / kSuper;
@@ -1887,6 +1984,7 @@ static int trace_impl(const RtgsScene* scene, const RtgsCamera* cam, const RtgsT
     a.bin_stride = bin_stride_of(nslabs_);
     a.bin_shift = g.shift;
     a.bin_sx = g.sx;
+    a.tile_bin = tile_bin_of(const_cast<int32_t*>(a.bin_count), nslabs_, cam->width, cam->height);
   }
   const float4* bbox = static_cast<const float4*>(workspace);
   const float4* rec = bbox + nn;
