@@ -21,12 +21,8 @@ echo "stamps done"
 {
   echo "# tools/shard_time.py (production build, HIP events, k_trace of rank 0's shard alone)"
   python tools/shard_time.py 2>&1 | grep shard
-  echo "# tools/split_sweep.py"
-  python tools/split_sweep.py c3 2>&1 | grep tiles
-  echo "# tools/graph_vs_direct.py"
-  python tools/graph_vs_direct.py c3 c5 2>&1 | grep shard
-  echo "# tools/host_overhead.py"
-  python tools/host_overhead.py 2>&1 | grep "us"
+  echo "# tools/shard_loop.py: rank 0 of 8's frame loop on one GPU (real loop + real RCCL call for one peer's worth / no gather)"
+  python tools/shard_loop.py c3 c5 2>&1 | grep "rank 0"
 } > $OUT/${RND}_shards.txt
 echo "shards done"
 rm -f $R/gpurun_out/variants/results.txt

@@ -11,12 +11,20 @@ with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as f:
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
     for r in rows:
         name = r["Name"]
-        short = "k_trace" if "k_trace" in name else "k_project" if "k_project" in name else name[:70]
+        short = next((k for k in ("k_trace", "k_project", "k_bin", "k_super_bbox") if k in name), name[:70])
         w.writerow([short, r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
-out = {"source": "rocprofv3 --kernel-trace --stats / --pmc (separate passes), python3 bench.py --no-cpu-baseline",
+import importlib.util
+_spec = importlib.util.spec_from_file_location("rtgs_build", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                           "rt-gaussian-splat-renderer_amd", "build.py"))
+_build = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(_build)
+out = {"source": "rocprofv3 --kernel-trace --stats / --pmc (separate passes), python3 bench.py --no-cpu-baseline --no-secondary",
+       # hash of csrc/* + include/rtgs_hip.h the profiled library was built from: bench.py only uses these counters
+       # when it is timing a build of the same sources
+       "source_hash": _build.source_hash(),
        "kernels": {}}
 for r in rows:
-    for k in ("k_trace", "k_project"):
+    for k in ("k_trace", "k_project", "k_bin", "k_super_bbox"):
         if k in r["Name"]:
             out["kernels"][k] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]),
                                  "max_ns": float(r["MaxNs"])}
