@@ -57,6 +57,27 @@ namespace {
 // XCD map no gain (round 2: one equal-count image WEDGE per XCD, most central tile first inside
 // it, is a gain -- rtgs_launch_order below); software-pipelining insertion(k) with the test of
 // k+1 0.329.
+// Round 3, measured and dropped (A/B builds of the same tree, tools/ab.sh; k_trace ms at c3 / c5):
+//  * candidate records double-buffered in SGPRs (candidate k+1's s_load_dwordx16 in flight while k is
+//    evaluated; 8 s_mov_b64 per candidate to rotate the buffers): 0.1346 -> 0.1440 / 1.305 -> 1.361;
+//  * a key-only K = 16 list -- ONE register per entry (t1 with its slot in the low 4 bits: an insertion is
+//    16 v_med3_u32 and nothing else), the index word in LDS, the exponent in private scratch, exact
+//    (t1, index) order restored on demand by bubble passes over entries with equal truncated t1 (parity
+//    suite green, also with 10 low bits masked so that those paths ran all the time; commit e0e02ed):
+//    SQ_INSTS_VALU 83.5 M -> 78.0 M per c3 launch, 0.1308 -> 0.1281 / 1.281 -> 1.344 -- and 137 MB of
+//    scratch writes per 1080p frame reach HBM (WRITE_SIZE 24.9 -> 162 MB): a 2 % gain for six times the
+//    memory traffic;
+//  * 2 or 4 slab bounds in flight per wave in the expansion (RTGS_EXPAND) with that list's free registers:
+//    0.1289 -> 0.1304 / 0.1307;
+//  * whole frames alternating over two streams on ONE GPU (frame f+1's k_project + k_bin in the shadow of
+//    frame f's k_trace): 0.1468 -> 0.1733 ms per frame at c3, 1.339 -> 1.369 at c5 (two resident k_trace
+//    grids thrash each other's L2).
+// What the counters say (profiles/r03_c3_summary.json): of a wave's 16 k quad-cycles 28 % are spent
+// issuing, 32 % stalled at issue behind the SIMD's other six waves, 40 % parked in s_waitcnt / barriers
+// (scan, expansion, compositing gathers).  Instruction issue is 60 % of the time and the vector
+// instructions two thirds of the issue, so a cut of x % of the VALU count returns about 0.4 x % of the
+// time -- which is what each of the experiments above and the macro-tile bins (scan phase 7.7 k -> 7.2 k
+// cycles: 0.1347 -> 0.1317) delivered.
 #ifndef RTGS_STAMPS
 #define RTGS_STAMPS 0     // diagnostic build: per-phase s_memtime stamps of wave 0 into the buffer
 #endif                    // passed as attenuation_buf (8 x u64 per block); never quote its run time
@@ -82,15 +103,6 @@ namespace {
 #define RTGS_LOOKAHEAD 1  // big scenes: touch the next candidate's record line one iteration ahead (scalar-cache
 #endif                    // prefetch).  c5 (64 MB of records) 1.74 -> 1.58 ms; c3 (6.4 MB, L2-resident) 0.188 -> 0.192: off there
 
-#ifndef RTGS_KLIST
-#define RTGS_KLIST 1      // K = 16 lists keep ONE register per entry (t1 with the slot in its low bits); see k_trace
-#endif
-#ifndef RTGS_KLIST_TIER
-#define RTGS_KLIST_TIER 0  // 1: the key-only list fills in two stages of 8 slots like the round-2 list (RTGS_TIER)
-#endif
-#ifndef RTGS_KLIST_LOW
-#define RTGS_KLIST_LOW 4  // low t1 bits that give way to the slot (test builds widen it: the exact-order paths then run all the time)
-#endif
 #ifndef RTGS_CUT_TRAVERSAL
 #define RTGS_CUT_TRAVERSAL 1   // t_cutoff > 0 also ends a tile's traversal (k_trace<..., kCut = true>)
 #endif
@@ -727,8 +739,6 @@ __device__ __forceinline__ unsigned wave_umin(unsigned h) { return ~wave_umax(~h
 __device__ __forceinline__ float exp_m3(float w) {
   return __builtin_amdgcn_exp2f(fmaf(w, 1.4426950408889634f, -4.3280851226668902f));
 }
-// median of three unsigned values (the compiler folds this form into one v_med3_u32)
-__device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) { return max(min(a, b), min(max(a, b), c)); }
 // HIP's __any() goes through an int (v_cndmask 0/1 + v_cmp_ne): the ballot form is the compare itself
 __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 // Per-lane list of the RTGS_MAX_DEPTH smallest entry distances: three register arrays (t1 bits,
@@ -750,12 +760,7 @@ __device__ __forceinline__ void list_insert_par(unsigned (&kt)[kK], unsigned (&k
                                                 unsigned tn, unsigned in, float wn) {
   bool lt[kK];
 #pragma unroll
-  for (int k = 0; k < kK; ++k) {
-    lt[k] = tn < kt[k];
-    // exactly equal t1: the lower index wins, the rule of the K = 16 list (a progressive sample() must peel
-    // the same Gaussian as the one-pass trace composites)
-    if constexpr (kK == 1) lt[k] = lt[k] || (tn == kt[k] && tn != ~0u && in < ki[k]);
-  }
+  for (int k = 0; k < kK; ++k) lt[k] = tn < kt[k];
 #pragma unroll
   for (int k = kK - 1; k > 0; --k) {
     kt[k] = lt[k - 1] ? kt[k - 1] : (lt[k] ? tn : kt[k]);
@@ -942,74 +947,18 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   float start = 0.f;
   if ((a.flags & RTGS_TRACE_RESUME) && in_img) start = a.start[((size_t)pi * a.height + pj) * a.start_stride];
 
-  // ---- the per-ray list of the kK nearest entries --------------------------------------------------
-  // kKL (round 3, the one-wave K = 16 form): ONE register per entry.  key[k] = t1's bits with the low
-  // kLow bits replaced by the entry's SLOT (0..15, a permutation over the list); the slot's data live
-  // outside the registers: s_w[slot][thread] (LDS) = index << 4 | the t1 bits that gave way, and the
-  // exponent in wpriv[slot] (private scratch: written once per insertion, read once at the end).
-  // Unsigned order of the keys = order of the truncated t1, so an insertion is 16 v_med3_u32 (8 in
-  // either half) and nothing else moves: the 16 compares + 32 selects that carried the payload along
-  // were half of k_trace's vector instructions.  EXACT order -- (t1, index), what the reference's
-  // strict `<` on fp32 t1 and a fixed tie rule give -- differs from key order only among entries whose
-  // t1 agree in all but the low bits (4e-5 of adjacent pairs at c3); those are put right by
-  // `normalise` (bubble passes on the LDS words) whenever it matters: before an eviction out of such
-  // a run, when a candidate ties with the last entry in the truncated bits, and before compositing.
-  // (not the SH instantiations: their time is the 180-B colour gathers of the compositing, which the list's
-  // LDS round trip and scratch reads lengthen -- c5 1.281 -> 1.344 ms with it, c3 0.1308 -> 0.1281)
-  constexpr bool kKL = RTGS_KLIST != 0 && kK == RTGS_MAX_DEPTH && kSplit == 1 && (!kHasSh || RTGS_KLIST == 2);
-  constexpr unsigned kLowMask = kKL ? (1u << RTGS_KLIST_LOW) - 1u : 0u;
-  static_assert(RTGS_KLIST_LOW >= 4 && RTGS_KLIST_LOW <= 16, "the slot needs 4 bits");
-  unsigned key[kK], kidx[kKL ? 1 : kK];
+  unsigned key[kK], kidx[kK];
   constexpr unsigned kEmpty = 0x7F800000u;  // +inf
   constexpr int kWn = kLdsW ? 1 : kK;
   float wexp[kWn];
 #pragma unroll
   for (int k = 0; k < kK; ++k) {
-    // kKL: empty slots are distinct values above +inf, in order, carrying their slot
-    key[k] = kKL ? kEmpty + ((unsigned)k << RTGS_KLIST_LOW) + (unsigned)k : kEmpty;
-    if constexpr (!kKL) kidx[k] = kLdsW ? (unsigned)k | ((unsigned)role << 4) : 0u;   // kLdsW: payload = entry << kSlotBits | slot
+    key[k] = kEmpty;
+    kidx[k] = kLdsW ? (unsigned)k | ((unsigned)role << 4) : 0u;   // kLdsW: payload = entry << kSlotBits | slot
   }
 #pragma unroll
   for (int k = 0; k < kWn; ++k) wexp[k] = 0.f;
   [[maybe_unused]] float* const s_wl = s_w + tid;
-  [[maybe_unused]] unsigned* const s_pl = reinterpret_cast<unsigned*>(s_w) + tid;   // kKL: the slot words
-  // kKL: exponents by slot in private memory (its address escapes into the asm, so the array stays a
-  // real scratch array with plain scratch_store / scratch_load instead of sixteen selects per access)
-  float wpriv[kKL ? kK : 1];
-  if constexpr (kKL) { float* esc = wpriv; asm volatile("" : "+v"(esc) : : "memory"); }
-  // exact order of two entries with equal truncated t1: (the bits that gave way, index)
-  [[maybe_unused]] auto exact_of = [](unsigned p) __attribute__((always_inline)) -> unsigned long long {
-    return ((unsigned long long)(p & kLowMask) << 32) | (p >> RTGS_KLIST_LOW);
-  };
-  [[maybe_unused]] auto same_trunc = [](unsigned a_, unsigned b_) __attribute__((always_inline)) -> bool { return (a_ ^ b_) <= kLowMask; };
-  // Bubble passes over adjacent entries with equal truncated t1 until key order IS exact order.  The
-  // keys never move (the insertion network needs them ascending as unsigned values): the two
-  // entries trade SLOTS' CONTENTS -- LDS word and exponent -- instead.
-  // (always_inline: as a called function it would force key[] into memory)
-  [[maybe_unused]] auto normalise = [&]() __attribute__((always_inline)) {
-    for (;;) {
-      bool swapped = false;
-#pragma unroll
-      for (int k = kK - 1; k > 0; --k) {
-        const bool eq = same_trunc(key[k - 1], key[k]) && key[k] < kEmpty;
-        if (wave_any(eq)) {
-          if (eq) {
-            const unsigned sa = key[k - 1] & 15u, sb = key[k] & 15u;
-            const unsigned pa = s_pl[sa * kBlock], pb = s_pl[sb * kBlock];
-            if (exact_of(pa) > exact_of(pb)) {
-              s_pl[sa * kBlock] = pb;
-              s_pl[sb * kBlock] = pa;
-              const float wa = wpriv[sa], wb2 = wpriv[sb];
-              wpriv[sa] = wb2;
-              wpriv[sb] = wa;
-              swapped = true;
-            }
-          }
-        }
-      }
-      if (!wave_any(swapped)) break;
-    }
-  };
   constexpr bool kHorizon = RTGS_HORIZON != 0 && kK == RTGS_MAX_DEPTH;
   static_assert(!kCut || (kSplit == 1 && kK == RTGS_MAX_DEPTH), "traversal cut: one-wave full-list form only");
   constexpr int kChunksMax = kListCap / kWave;
@@ -1019,9 +968,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
     if ((a.flags & RTGS_TRACE_RESUME) && in_img) T_in = a.att[(size_t)pi * a.height + pj];
   }
   constexpr bool kLookahead = RTGS_LOOKAHEAD == 2 || (RTGS_LOOKAHEAD == 1 && kBig);
-  // (kKL: an insertion is 16 v_med3_u32 -- filling in two stages costs more in branches than it saves:
-  // c3 0.1305 -> 0.1286 ms, c5 1.373 -> 1.344 without)
-  constexpr int kTier = (kLdsW && !(kKL && RTGS_KLIST_TIER == 0) && RTGS_TIER > 0 && RTGS_TIER < kK) ? RTGS_TIER : kK;
+  constexpr int kTier = (kLdsW && RTGS_TIER > 0 && RTGS_TIER < kK) ? RTGS_TIER : kK;
   [[maybe_unused]] bool tier_short = kTier < kK;   // wave-uniform: slot kTier-1 still empty in every lane
 
   // set bits of a wave mask below this lane: v_mbcnt_lo/hi straight from the SGPR pair
@@ -1301,31 +1248,15 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
             float Tp = T_in;
             int nh = 0;
             unsigned prev = 0u;
-            if constexpr (kKL) {   // exact order first: a repeated t1 is only recognised next to its twin
-              bool anyeq = false;
-#pragma unroll
-              for (int k = 1; k < kK; ++k) anyeq |= same_trunc(key[k - 1], key[k]) && key[k] < kEmpty;
-              if (wave_any(anyeq)) normalise();
-            }
 #pragma unroll
             for (int k = 0; k < kK; ++k) {
-              unsigned tb = key[k], pw = 0u;
-              if constexpr (kKL) {
-                if (tb < kEmpty) { pw = s_pl[(tb & 15u) * kBlock]; tb = (tb & ~kLowMask) | (pw & kLowMask); }
-              }
+              const unsigned tb = key[k];
               const bool fin = tb < bnd;                       // final: nothing to come can precede it
               const bool valid = fin && tb != prev && nh < a.depth;
               prev = tb;
               if (wave_any(valid && !(Tp < a.t_cutoff))) {
-                float op, wv;
-                if constexpr (kKL) {
-                  op = fin ? colop[pw >> RTGS_KLIST_LOW].w : 0.f;
-                  wv = wpriv[key[k] & 15u];
-                } else {
-                  op = fin ? colop[(kidx[k] >> kSlotBits)].w : 0.f;
-                  wv = s_wl[(kidx[k] & 15u) * kBlock];
-                }
-                const float alpha = op * exp_m3(wv);
+                const float op = fin ? colop[(kidx[k] >> kSlotBits)].w : 0.f;
+                const float alpha = op * exp_m3(s_wl[(kidx[k] & 15u) * kBlock]);
                 if (valid && !(Tp < a.t_cutoff)) { Tp *= 1.0f - alpha; ++nh; }
               }
             }
@@ -1354,8 +1285,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
             // (capture-like, tools/cap_sweep.py) lose most of their candidates here.
             // (while some list is not full the horizon is +inf: one compare + ballot instead of the reduction)
             const bool open_list = wave_any(in_img && key[kK - 1] >= kEmpty);
-            // (kKL: the key is the truncated t1 + slot; with the low bits set it is at or above the entry's t1)
-            const unsigned hz = open_list ? kEmpty : wave_umax(in_img ? (key[kK - 1] | kLowMask) : 0u);   // t1 bits
+            const unsigned hz = open_list ? kEmpty : wave_umax(in_img ? key[kK - 1] : 0u);   // t1 bits
             // (evaluated even while hz is still +inf: this chunk's loads are all consumed before
             // the next chunk's are issued, so nothing inside the candidate loop waits for memory)
             m &= __ballot(tm < __uint_as_float(min(hz, kEmpty)) || hz >= kEmpty);
@@ -1446,11 +1376,9 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
 #endif
             // scene.py:433: start < t1 < end, end = +inf for a camera ray (an overflowed t1 = +inf has the
             // bits of an empty slot and fails the insertion test below by itself; NaN fails `>`)
-            const bool cand = hit && t1 > start && (!kKL || t1 < kInf);   // (kKL: empty slots are not exactly +inf)
+            const bool cand = hit && t1 > start;
             const unsigned kn = cand ? __float_as_uint(t1) : ~0u;
-            // kKL: `ins` = the truncated t1 is below (or, to be settled exactly, equal to) the last entry's
-            [[maybe_unused]] const unsigned klast = kKL ? (tier_short ? key[kTier - 1] : key[kK - 1]) : 0u;
-            const bool ins = kKL ? (kn | kLowMask) <= (klast | kLowMask) : kn < key[kK - 1];
+            const bool ins = kn < key[kK - 1];
 #if RTGS_COUNT
             n_hit_lanes += (unsigned)__popcll(__ballot(cand));
             n_ins_lanes += (unsigned)__popcll(__ballot(ins));
@@ -1479,55 +1407,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
                 const unsigned rank = (unsigned)(turn0 + __popcll(m_all & ((1ull << b) - 1ull)));
                 entry |= rank << a.idx_bits;
               }
-              if constexpr (kKL) {
-                // strictly below the last entry in the truncated bits: a plain insertion, the last entry
-                // falls off and the new one takes its slot -- unless the list ends in a run of equal
-                // truncated t1 (then which of them is last has to be settled first); equal to it in the
-                // truncated bits: the exact comparison decides, in place.  Both are rare: one ballot.
-                bool lt = (kn | kLowMask) < klast;
-                // (wave masks straight from the compares: per-lane bools would be materialised in VGPRs)
-                const unsigned long long m_lt = __builtin_amdgcn_ballot_w64(lt);
-                unsigned long long m_slow = __builtin_amdgcn_ballot_w64(ins) & ~m_lt;          // ties with the last entry
-                if (!tier_short) m_slow |= m_lt & __builtin_amdgcn_ballot_w64(same_trunc(key[kK - 2], key[kK - 1]));
-                unsigned last = klast;
-                if (__builtin_expect(m_slow != 0ull, 0)) {
-                  normalise();
-                  last = tier_short ? key[kTier - 1] : key[kK - 1];
-                  lt = (kn | kLowMask) < last;
-                  if (cand && !lt && same_trunc(kn | kLowMask, last | kLowMask)) {
-                    // same truncated t1 as the (exactly) last entry: the smaller of the two in (t1, index) stays
-                    const unsigned sl = last & 15u;
-                    const unsigned pnew = ((unsigned)gi << RTGS_KLIST_LOW) | (kn & kLowMask);
-                    if (exact_of(pnew) < exact_of(s_pl[sl * kBlock])) {
-                      s_pl[sl * kBlock] = pnew;
-                      wpriv[sl] = wn;
-                    }
-                  }
-                }
-                const unsigned slot = last & 15u;
-                const unsigned kq = lt ? ((kn & ~kLowMask) | slot) : ~0u;
-                if (lt) {
-                  s_pl[slot * kBlock] = ((unsigned)gi << RTGS_KLIST_LOW) | (kn & kLowMask);
-                  wpriv[slot] = wn;
-                }
-                // the keys are distinct unsigned values in ascending order: slot k becomes the median of
-                // (left neighbour, itself, new key); lanes that do not insert carry ~0 and change nothing
-                const bool low = kTier == kK || tier_short || wave_any(kq < key[kTier - 1]);
-                if constexpr (kTier < kK) {
-                  if (!tier_short) {
-#pragma unroll
-                    for (int k = kK - 1; k >= kTier; --k) key[k] = umed3(key[k - 1], key[k], kq);
-                  }
-                }
-                if (low) {
-#pragma unroll
-                  for (int k = kTier - 1; k > 0; --k) key[k] = umed3(key[k - 1], key[k], kq);
-                  key[0] = min(key[0], kq);
-                }
-                if constexpr (kTier < kK) {
-                  if (tier_short) tier_short = !wave_any(key[kTier - 1] < kEmpty);
-                }
-              } else if constexpr (kLdsW) {
+              if constexpr (kLdsW) {
                 // the new entry takes the exponent slot of the entry that falls off the end
                 const unsigned slot = (tier_short ? kidx[kTier - 1] : kidx[kK - 1]) & kSlotMask;
                 const unsigned pn = (entry << kSlotBits) | slot;
@@ -1676,26 +1556,6 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
     sh_basis(wx * in, wy * in, wz * in, Ysh);
   }
   [[maybe_unused]] const unsigned idx_mask = kSplit == 2 ? (1u << ea->idx_bits) - 1u : ~0u;
-  if constexpr (kKL) {   // exact (t1, index) order among entries whose truncated t1 agree (rare: one ballot)
-    bool anyeq = false;
-#pragma unroll
-    for (int k = 1; k < kK; ++k) anyeq |= same_trunc(key[k - 1], key[k]) && key[k] < kEmpty;
-    if (__builtin_expect(wave_any(anyeq), 0)) normalise();
-  }
-  // kKL: the 16 slot words in one LDS round trip (the candidate loop's registers are free now); from here
-  // on key[k] holds the entry's full t1 bits and pword[k] its index, as the register lists of round 2 did
-  // (32 registers, what the round-2 lists held: the slot moves into the low bits the t1 bits leave free)
-  [[maybe_unused]] unsigned pword[kKL ? kK : 1];
-  if constexpr (kKL) {
-#pragma unroll
-    for (int k = 0; k < kK; ++k) pword[k] = key[k] < kEmpty ? s_pl[(key[k] & 15u) * kBlock] : 0u;
-#pragma unroll
-    for (int k = 0; k < kK; ++k) {
-      const unsigned slot = key[k] & 15u;
-      if (key[k] < kEmpty) key[k] = (key[k] & ~kLowMask) | (pword[k] & kLowMask);
-      pword[k] = (pword[k] & ~kLowMask) | slot;
-    }
-  }
   int nhit = 0;
   float last_t = 0.f;
   unsigned prev_tbits = 0u;
@@ -1715,33 +1575,22 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
 #endif
     float4 cog[kGroup];
     [[maybe_unused]] float wl[kGroup];
-    if constexpr (kKL) {
-#pragma unroll
-      for (int j = 0; j < kGroup; ++j) wl[j] = wpriv[pword[k0 + j] & 15u];
-    }
 #pragma unroll
     for (int j = 0; j < kGroup; ++j) {
       const int k = k0 + j;
       const unsigned tb = key[k];
-      unsigned gi;
-      if constexpr (kKL) gi = pword[k] >> RTGS_KLIST_LOW;
-      else gi = kLdsW ? (kidx[k] >> kSlotBits) & idx_mask : kidx[k];
+      const unsigned gi = kLdsW ? (kidx[k] >> kSlotBits) & idx_mask : kidx[k];
       cog[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (tb < kEmpty) cog[j] = colop[gi];
       // the exponent: slot (kidx & 15) of this lane's column, or of the helper wave's (bit 4)
-      if constexpr (kLdsW && !kKL) wl[j] = s_wl[(kidx[k] & 15u) * kBlock + (kSplit == 2 ? ((kidx[k] >> 4) & 1u) * kTraceBlock : 0u)];
+      if constexpr (kLdsW) wl[j] = s_wl[(kidx[k] & 15u) * kBlock + (kSplit == 2 ? ((kidx[k] >> 4) & 1u) * kTraceBlock : 0u)];
     }
 #pragma unroll
     for (int j = 0; j < kGroup; ++j) {
       const int k = k0 + j;
       if (!done) {
         const unsigned tbits = key[k];
-        unsigned gi;
-        if constexpr (kKL) {
-          gi = pword[k] >> RTGS_KLIST_LOW;
-        } else {
-          gi = kLdsW ? (kidx[k] >> kSlotBits) & idx_mask : kidx[k];
-        }
+        const unsigned gi = kLdsW ? (kidx[k] >> kSlotBits) & idx_mask : kidx[k];
         // an exact repeat of the previous entry distance is what the reference's strict
         // `t1 > ray.start` drops (scene.py:433 after ray_tracer.py:101)
         const bool valid = tbits < kEmpty && tbits != prev_tbits && nhit < ea->depth;
@@ -1867,9 +1716,8 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
     if (ea->start) {
       float s_out = (nhit == ea->depth) ? last_t + 1e-8f : kInf;
       if constexpr (kK > 1) {
-        if (nhit < ea->depth && key[kK - 1] < kEmpty && !(ea->t_cutoff > 0.f && T < ea->t_cutoff)) {
-          s_out = __uint_as_float(key[kK - 1]) + 1e-8f;   // (kKL: rebuilt to the full t1 bits before compositing)
-        }
+        if (nhit < ea->depth && key[kK - 1] < kEmpty && !(ea->t_cutoff > 0.f && T < ea->t_cutoff))
+          s_out = __uint_as_float(key[kK - 1]) + 1e-8f;
       }
       ea->start[pix * ea->start_stride] = s_out;
     }
@@ -2186,13 +2034,6 @@ static int trace_impl(const RtgsScene* scene, const RtgsCamera* cam, const RtgsT
   // the cut-off's traversal cut has its own instantiation of the one-wave full-list form
   const bool cut = RTGS_CUT_TRAVERSAL != 0 && params->t_cutoff > 0.f && params->depth > 1;
   if (a.idx_bits > 17) split = false;   // two-wave entries: rank | index | 5 slot bits in 32; 10 rank bits need n <= 131072
-#if RTGS_KLIST
-  // Round 3: the key-only list (k_trace, kKL) made the one-wave form faster than the two-wave form at
-  // every launch size, and small shards now overlap whole frames (rtgs.parallel: F frames in flight)
-  // instead of splitting tiles; the two-wave form is retired, its flags are accepted and ignored
-  // (they only ever chose a schedule: same pixels).
-  split = false;
-#endif
 #define RTGS_LAUNCH(HAS_SH, BIG, K, SPLIT)                                                         \
   hipLaunchKernelGGL((k_trace<HAS_SH, BIG, K, SPLIT>), dim3(local), dim3(kTraceBlock * SPLIT), 0, s, a, \
                      bbox, slab_bbox, super_bbox, rec, tail, tmin, colop, sh)
@@ -2201,7 +2042,7 @@ static int trace_impl(const RtgsScene* scene, const RtgsCamera* cam, const RtgsT
     if (cut) hipLaunchKernelGGL((k_trace<HAS_SH, BIG, RTGS_MAX_DEPTH, 1, true>), dim3(local), dim3(kTraceBlock), 0, s, a, \
                                 bbox, slab_bbox, super_bbox, rec, tail, tmin, colop, sh);                                \
     else if (params->depth == 1) RTGS_LAUNCH(HAS_SH, BIG, 1, 1);                    \
-    else if (split) RTGS_LAUNCH(HAS_SH, BIG, RTGS_MAX_DEPTH, (RTGS_KLIST ? 1 : 2));   \
+    else if (split) RTGS_LAUNCH(HAS_SH, BIG, RTGS_MAX_DEPTH, 2);                    \
     else RTGS_LAUNCH(HAS_SH, BIG, RTGS_MAX_DEPTH, 1);                               \
   } while (0)
   if (sh) { if (big) RTGS_LAUNCH_K(true, true); else RTGS_LAUNCH_K(true, false); }
