@@ -72,6 +72,10 @@ namespace {
 //  * whole frames alternating over two streams on ONE GPU (frame f+1's k_project + k_bin in the shadow of
 //    frame f's k_trace): 0.1468 -> 0.1733 ms per frame at c3, 1.339 -> 1.369 at c5 (two resident k_trace
 //    grids thrash each other's L2).
+//  * supertile bins filled by k_project itself (every slab appends its id to the bins it touches with one
+//    atomic per supertile; no k_bin launch; tiles rank-sort what they keep): project + bin 17.2 -> 15.0 us,
+//    but k_trace 0.1325 -> 0.1465 / 1.304 -> 1.452 -- the per-tile rank sort (two barriers, n^2 LDS reads)
+//    costs every tile what k_bin's one sort per supertile saves.
 // What the counters say (profiles/r03_c3_summary.json): of a wave's 16 k quad-cycles 28 % are spent
 // issuing, 32 % stalled at issue behind the SIMD's other six waves, 40 % parked in s_waitcnt / barriers
 // (scan, expansion, compositing gathers).  Instruction issue is 60 % of the time and the vector
