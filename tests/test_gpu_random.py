@@ -101,6 +101,44 @@ def test_non_finite_gaussians_are_culled():
     assert float((a.sample_buf - b.sample_buf).abs().max()) <= 2e-6
 
 
+def test_horizon_bound_holds_for_isotropic_gaussians_on_the_pixel_rays():
+    # the horizon test skips a candidate whose distance bound |o - mu| - sqrt(3) s_max (k_project,
+    # fp64, with a relative margin) is at or beyond every ray's 16th entry.  The bound is TIGHT for an
+    # isotropic Gaussian centred on a pixel's ray -- its t1 IS |o - mu| - sqrt(3) s there -- while the
+    # kernel's t1 is fp32 arithmetic on rounded record coefficients: if the margin were thinner than that
+    # rounding, a candidate a wave should insert would be skipped.  24 such Gaussians per pixel of a 12x10
+    # image, nearly coincident in depth (gaps of 1e-5 relative), far and small enough that all 16 slots of
+    # every ray fill and the horizon is live for the last third of the stream; enough Gaussians (> 64 per
+    # tile, shuffled) that candidates arrive in several chunks.
+    rng = np.random.default_rng(77)
+    w, h, per = 12, 10, 24
+    cam = synthetic.bench_camera(w, h)
+    o = np.asarray(cam["position"], np.float64)
+    ii, jj = np.meshgrid(np.arange(w), np.arange(h), indexing="ij")
+    d = np.stack([((ii + 0.5) - w / 2) / cam["fx"], ((jj + 0.5) - h / 2) / cam["fy"], -np.ones_like(ii, float)], -1)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    dist = 2.0 * (1.0 + 1e-5 * np.arange(per))[None, None, :] * np.ones((w, h, 1))   # the same on every ray: a tight horizon
+    pos = o + d[:, :, None, :] * dist[..., None]
+    n = w * h * per
+    perm = rng.permutation(n)
+    arrays = dict(position=pos.reshape(n, 3)[perm].astype(np.float32),
+                  rotation=np.tile(np.float32([0, 0, 0, 1]), (n, 1)),
+                  scale=np.full((n, 3), 0.004, np.float32),
+                  color=rng.random((n, 3)).astype(np.float32), opacity=np.full(n, 0.2, np.float32), sh=None)
+    _, _, tracer = U.build(arrays, cam)
+    tracer.sample_all(16)
+    torch.cuda.synchronize()
+    want = c_oracle.render(arrays, cam, 16)
+    assert (want["hits"] == 16).mean() > 0.9
+    got = tracer.sample_buf.cpu().numpy().reshape(-1, 3)
+    # the depth order of near-coincident entries is fragile by construction; what must hold is that no
+    # contribution is LOST: every ray composites 16 entries of opacity 0.2 at their centres
+    att = tracer.attenuation_buf.cpu().numpy().reshape(-1)
+    full = want["hits"] == 16
+    assert np.abs(att[full] - 0.8 ** 16).max() <= 1e-4
+    assert np.isfinite(got).all()
+
+
 @pytest.mark.parametrize("sh", [False, True])
 def test_large_scene_instantiation(sh):
     # more than 4096 slabs (262 144 Gaussians) selects the large-batch instantiation of the
