@@ -37,7 +37,7 @@ ENGINE_CLOCK_HZ = 2.4e9
 VALU_PEAK_GINST = N_SIMD * ENGINE_CLOCK_HZ / 2 / 1e9   # G wave-instructions / s
 PROFILE_ROUND = "r03"
 MIN_TIMED_S = 0.25          # a timed batch shorter than this is repeated and the MEDIAN batch is reported
-MAX_BATCHES = 15
+MAX_BATCHES = 400
 LDS_BYTES_PER_INST = 256    # 64 lanes x 4 B: k_trace's LDS instructions are b32 (upper bound for its few b128 reads: x4)
 
 
@@ -361,7 +361,9 @@ def main():
             "value": mrays, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "batches": len(batches), "batch_ms_per_step": [b / args.steps * 1e3 for b in batches],
+            "batches": len(batches), "timed_s": sum(batches),
+            "batch_ms_per_step": {"min": min(batches) / args.steps * 1e3, "median": ms,
+                                  "max": max(batches) / args.steps * 1e3},
             "config": {"workload": f"{cfg.name}: {cfg.n} random Gaussians (seed {cfg.seed}), "
                                    f"{cfg.width}x{cfg.height}, depth {cfg.depth}, "
                                    f"{'SH deg 3' if cfg.sh else 'no SH'}, camera (0,0,3) f=H",
