@@ -699,29 +699,43 @@ __global__ __launch_bounds__(256) void k_bin(int32_t nslabs, const float4* __res
       if (rank[q] >= 0) { s_bb[rank[q]] = mybb[q]; s_sid[rank[q]] = s_id[tid + q * 256]; }
     __syncthreads();
     const int per_edge = 1 << shift, ntl = per_edge * per_edge;
-    for (int t = wave; t < ntl; t += 4) {
-      const int tx = (st % bin_sx) * per_edge + (t % per_edge), ty = (st / bin_sx) * per_edge + (t / per_edge);
-      if (tx >= tiles_x || ty >= tiles_y) continue;
-      const int mi0 = tx * kTile, mj0 = ty * kTile;
-      const float tXlo = ((float)mi0 + 0.5f) - hw, tXhi = ((float)min(mi0 + kTile, width) - 0.5f) - hw;
-      const float tYlo = ((float)mj0 + 0.5f) - hh, tYhi = ((float)min(mj0 + kTile, height) - 0.5f) - hh;
-      int32_t* const out = tile_bin + (size_t)(ty * tiles_x + tx) * kTileBinCap;
-      int n = 0;
+    // four tiles at a time per wave: one pass over the sorted list serves all four (the list entries are
+    // read once, the four compaction chains are independent)
+    for (int t0 = wave * 4; t0 < ntl; t0 += 16) {
+      float tXlo[4], tXhi[4], tYlo[4], tYhi[4];
+      int32_t* out[4];
+      int n[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int t = t0 + q;
+        const int tx = (st % bin_sx) * per_edge + (t % per_edge), ty = (st / bin_sx) * per_edge + (t / per_edge);
+        const bool in = t < ntl && tx < tiles_x && ty < tiles_y;
+        const int mi0 = tx * kTile, mj0 = ty * kTile;
+        // (a tile outside the frame gets bounds nothing overlaps and no output)
+        tXlo[q] = in ? ((float)mi0 + 0.5f) - hw : kInf;
+        tXhi[q] = in ? ((float)min(mi0 + kTile, width) - 0.5f) - hw : -kInf;
+        tYlo[q] = in ? ((float)mj0 + 0.5f) - hh : kInf;
+        tYhi[q] = in ? ((float)min(mj0 + kTile, height) - 0.5f) - hh : -kInf;
+        out[q] = in ? tile_bin + (size_t)(ty * tiles_x + tx) * kTileBinCap : nullptr;
+        n[q] = 0;
+      }
       for (int base = 0; base < cnt; base += kWave) {
         const int e = base + lane;
-        bool keep = false;
+        float4 b = make_float4(kInf, kInf, -kInf, -kInf);
         int id = 0;
-        if (e < cnt) {
-          const float4 b = s_bb[e];
-          id = s_sid[e];
-          keep = b.x <= tXhi && b.z >= tXlo && b.y <= tYhi && b.w >= tYlo;
+        if (e < cnt) { b = s_bb[e]; id = s_sid[e]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool keep = b.x <= tXhi[q] && b.z >= tXlo[q] && b.y <= tYhi[q] && b.w >= tYlo[q];
+          const unsigned long long km2 = __ballot(keep);
+          const int at = n[q] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(km2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km2, 0u));
+          if (keep && at < kTileBinCap - 1) out[q][1 + at] = id;
+          n[q] += __popcll(km2);
         }
-        const unsigned long long km2 = __ballot(keep);
-        const int at = n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(km2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km2, 0u));
-        if (keep && at < kTileBinCap - 1) out[1 + at] = id;
-        n += __popcll(km2);
       }
-      if (lane == 0) out[0] = n <= kTileBinCap - 1 ? n : -1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (lane == 0 && out[q]) out[q][0] = n[q] <= kTileBinCap - 1 ? n[q] : -1;
     }
   }
 }
