@@ -76,6 +76,9 @@ namespace {
 //    atomic per supertile; no k_bin launch; tiles rank-sort what they keep): project + bin 17.2 -> 15.0 us,
 //    but k_trace 0.1325 -> 0.1465 / 1.304 -> 1.452 -- the per-tile rank sort (two barriers, n^2 LDS reads)
 //    costs every tile what k_bin's one sort per supertile saves.
+//  * the candidate loop in two instantiations, with and without the class-1 (general conic) code, chosen per
+//    chunk from a class bit fetched with the distance bounds: the duplicated loop body costs the 72-VGPR
+//    main instantiation 57 spilled registers (0.1313 -> 0.1920); the uncapped ones grow by 5-16 VGPRs.
 // What the counters say (profiles/r03_c3_summary.json): of a wave's 16 k quad-cycles 28 % are spent
 // issuing, 32 % stalled at issue behind the SIMD's other six waves, 40 % parked in s_waitcnt / barriers
 // (scan, expansion, compositing gathers).  Instruction issue is 60 % of the time and the vector
