@@ -28,5 +28,7 @@ echo "shards done"
 rm -f $R/gpurun_out/variants/results.txt
 tools/variants.sh "full:" "ablate1_no_insertion:-DRTGS_ABLATE=1" "ablate2_no_hit_path:-DRTGS_ABLATE=2" "ablate3_no_candidate_loop:-DRTGS_ABLATE=3" "ablate4_scan_only:-DRTGS_ABLATE=4" > /dev/null 2>&1
 cp $R/gpurun_out/variants/results.txt $OUT/${RND}_c3_ablation.txt
+# (the summaries just made go where bench.py looks for them, so that the lines below carry roofline.frac)
+cp $OUT/${RND}_c3_summary.json $OUT/${RND}_c5_summary.json $R/profiles/
 for c in c1 c2 c3 c5 cap c3sh; do python bench.py --config $c --no-cpu-baseline 2>/dev/null | tail -1; done > $OUT/${RND}_bench_lines_n1.jsonl
 ls $OUT
