@@ -195,3 +195,48 @@ def test_driver_entry_points_exist_and_fail_loudly_without_a_gpu():
         run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"],
                              capture_output=True, text=True)
         assert run.returncode != 0 and "HIP device" in (run.stderr + run.stdout)
+
+
+def test_bench_uses_profiled_counters_only_for_the_build_they_were_profiled_on(tmp_path, monkeypatch):
+    # roofline.frac divides a counter from profiles/ by a live kernel time; the summary
+    # carries the hash of the sources it was profiled on (build.source_hash, written by
+    # tools/summarize_prof.py) and bench.py refuses counters of any other build
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    h, count_lib = bench.source_hash()
+    assert len(h) == 16 and int(h, 16) >= 0 and count_lib.endswith("librtgs_hip_count.so")
+    assert bench.source_hash()[0] == h                      # a function of the files alone
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    summary = {"source_hash": h, "kernels": {"k_trace": {"pmc_mean_per_launch": {"SQ_INSTS_VALU": 8.0e7, "SQ_INSTS_LDS": 1.0e6}}},
+               "k_trace_hbm_bytes_per_launch": {"traffic_upper": 5.0e7}}
+    (prof / f"{bench.PROFILE_ROUND}_c3_summary.json").write_text(json.dumps(summary))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    got = bench.profiled_counters("c3", 1, h)
+    assert got["valu"] == 8.0e7 and got["lds"] == 1.0e6 and got["traffic"] == 5.0e7 and got["stale"] is None
+    stale = bench.profiled_counters("c3", 1, "0" * 16)
+    assert stale["valu"] is None and stale["traffic"] is None and "source hash" in stale["stale"]
+    assert bench.profiled_counters("c3", 2, h)["valu"] is None          # counters are of a one-GPU launch
+    assert bench.profiled_counters("c5", 1, h) == {"valu": None, "lds": None, "traffic": None, "source": None, "stale": None}
+
+
+def test_build_is_keyed_on_the_source_hash_not_on_mtimes(tmp_path):
+    # build() used to skip when the .so was newer than the sources; now the stamp
+    # beside the library must equal the hash of csrc/* + include/rtgs_hip.h
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("rtgs_build", os.path.join(root, "rt-gaussian-splat-renderer_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    lib = tmp_path / "lib.so"
+    lib.write_bytes(b"x")
+    assert not b._stamp_ok(str(lib))                         # no stamp: rebuild
+    (tmp_path / "lib.so.srchash").write_text("0" * 16 + "\n")
+    assert not b._stamp_ok(str(lib))                         # another tree's stamp: rebuild
+    (tmp_path / "lib.so.srchash").write_text(b.source_hash() + "\n")
+    assert b._stamp_ok(str(lib))
+    assert b._stamp_ok(b.LIB) and b._stamp_ok(b.COUNT_LIB)   # what build() left in the tree is current
