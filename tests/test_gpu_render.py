@@ -836,6 +836,48 @@ def test_frames_in_flight_keep_stream_order_without_host_syncs(in_flight, batch)
     r0.close()
 
 
+@pytest.mark.parametrize("cut", [0.0, 0.02])
+def test_tile_parallel_renderer_at_depth_24(cut):
+    # depth above RTGS_MAX_DEPTH through the tile-parallel paths: HipBackend.trace (world 1) and
+    # rtgs_shard_frame (world 4, two frames in flight, two per gather) carry one (attenuation, ray.start)
+    # pair per frame in flight through the chain of launches; with and without the transmittance cut-off
+    from oracle import c_oracle
+    from rtgs.parallel import TileParallelRenderer
+    depth = 24
+    arrays = synthetic.make_scene(2500, 1.0, 78)
+    arrays["scale"] = (arrays["scale"] * np.float32(2.0)).astype(np.float32)
+    arrays["opacity"] = (0.3 * arrays["opacity"]).astype(np.float32)
+    cam = synthetic.bench_camera(48, 40)
+    scene, camera, tracer = U.build(arrays, cam)
+    want = c_oracle.render(arrays, cam, depth, t_cutoff=cut)
+    assert (want["hits"] > 16).mean() > 0.5
+    one = TileParallelRenderer(scene, camera, depth=depth, rank=0, world=1, t_cutoff=cut)
+    one.render_frame()
+    one.finish()
+    torch.cuda.synchronize()
+    U.assert_parity(one.framebuffer.cpu().numpy().reshape(-1, 3), want, f"depth {depth}, world 1, cut {cut}")
+    world, T = 4, nat.tile_size()
+    per = (nat.lib().rtgs_num_tiles(cam["width"], cam["height"]) + world - 1) // world
+    shards = []
+    for _ in range(3):                       # three identical frames: the peers' shards, rendered beforehand
+        row = [None]
+        for r in range(1, world):
+            sh = torch.zeros((per, T, T, 3), dtype=torch.float32, device="cuda")
+            tracer.trace(depth, t_cutoff=cut, flags=nat.TRACE_COMPACT, tile_first=r, tile_step=world, sample_buf=sh)
+            row.append(sh)
+        shards.append(row)
+    torch.cuda.synchronize()
+    comm = _StreamOrderedComm(shards, 2)
+    r0 = TileParallelRenderer(scene, camera, depth=depth, rank=0, world=world, t_cutoff=cut, gather_fn=comm.gather,
+                              frames_in_flight=2, gather_batch=2)
+    for _ in range(3):
+        r0.render_frame()
+    r0.finish()
+    torch.cuda.synchronize()
+    assert torch.equal(r0.framebuffer, one.framebuffer)
+    r0.close()
+
+
 def test_frame_graph_replays_with_new_poses():
     # one captured hipGraph of [pose upload, rtgs_project, rtgs_trace] per shard; the pose travels
     # through RtgsCamera.device_pose, so replays follow a moving camera (position AND rotation, SH
