@@ -547,10 +547,11 @@ __global__ __launch_bounds__(256) void k_super_bbox(int32_t nslabs, const float4
 // ------------------------------------------------------------------------------------
 constexpr int kBinCapMax = 1024;          // slabs a bin can list; more = overflow, the tiles fall back to scanning
 #ifndef RTGS_BIN_GROUPS
-#define RTGS_BIN_GROUPS 4096   // 16-slab groups a supertile can keep in k_bin<true> (65 k slabs = 4 M Gaussians' worth);
-#endif                         // more = overflow, its tiles scan for themselves (1024 measures the same at c5)
+#define RTGS_BIN_GROUPS 1024   // 16-slab groups a supertile can keep in k_bin<true> (16 k slabs = 1 M Gaussians' worth);
+#endif                         // more = overflow, its tiles scan for themselves.  (4096: 12 KB more LDS, a workgroup per
+                               // CU fewer now that the listed slabs' bounds are kept too: c5 project + bin 63.1 -> 58.6 us)
 #ifndef RTGS_BIN_ITERS
-#define RTGS_BIN_ITERS 4
+#define RTGS_BIN_ITERS 8       // slab bounds in flight per thread: c3's 1 563 slabs are ONE step (4: two; 16.3 -> 15.8 us)
 #endif
 constexpr int kBinIters = RTGS_BIN_ITERS;
 
