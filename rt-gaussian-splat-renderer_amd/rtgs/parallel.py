@@ -16,7 +16,6 @@ from __future__ import annotations
 
 import os
 
-import numpy as np
 import torch
 import torch.distributed as dist
 
