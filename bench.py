@@ -7,7 +7,13 @@
 A step = one full frame of the hot path: per-frame projection + trace/sort/composite of every
 pixel (depth 16) and, for N > 1, the RCCL gather of the tile shards and the de-interleave on
 rank 0.  Scene and framebuffers are resident in HBM when the timed region starts.  One JSON
-line is printed by rank 0.  For N > 1 launch with torch.distributed.run (one rank per GPU).
+line is printed by rank 0.
+
+N > 1: one rank per GPU.  Launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* in the environment) the process IS a rank; launched bare (`python bench.py --gpus N`)
+it starts its N ranks itself -- child processes created BEFORE this process has touched the GPU
+(torch is not even imported in the parent), whose rank 0 prints the line -- and exits with their
+status: non-zero when a rank failed, timed out or the frames did not verify.
 """
 
 from __future__ import annotations
@@ -15,6 +21,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,9 +31,9 @@ for p in (os.path.join(ROOT, "rt-gaussian-splat-renderer_amd"), ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
+# numpy / torch / torch.distributed are imported by rank_main(): the launcher half of this file
+# (spawn_ranks) must stay free of anything that could initialise the GPU in the parent
+np = torch = dist = None
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 # VALU issue peak: 256 CUs x 4 SIMDs, one wave64 VALU instruction per SIMD every 2 cycles
@@ -41,7 +49,7 @@ MAX_BATCHES = 400
 LDS_BYTES_PER_INST = 256    # 64 lanes x 4 B: k_trace's LDS instructions are b32 (upper bound for its few b128 reads: x4)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -55,7 +63,79 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo "
                     "only for functional rehearsal of the N > 1 path)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: all ranks on cuda:0")
-    return ap.parse_args()
+    ap.add_argument("--dist-timeout", type=float, default=300.0, help="seconds: rendezvous and every collective "
+                    "(init_process_group timeout)")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds the self-spawned ranks get "
+                    "before the launcher ends them and exits 124")
+    return ap.parse_args(argv)
+
+
+# ---- launcher: `python bench.py --gpus N` with no WORLD_SIZE in the environment -------------------
+
+EXIT_UNVERIFIED = 2      # the N > 1 frames did not equal the single-rank render
+EXIT_TIMEOUT = 124
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def rank_env(rank: int, world: int, port: int, base=None) -> dict:
+    """The environment torch.distributed.run would give rank `rank` of one node."""
+    env = dict(os.environ if base is None else base)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
+    return env
+
+
+def spawn_ranks(world: int, argv, script=None, python=None, timeout: float = 1500.0, stdout=None, stderr=None,
+                poll_s: float = 0.05) -> int:
+    """Start `world` fresh child processes `python script *argv`, one per rank, and wait for them.
+    Returns 0 when every rank exited 0; otherwise the first failing rank's status (a signal's
+    number negated becomes 128 + signal), EXIT_TIMEOUT after `timeout` seconds -- and in both
+    cases the ranks still running are ended (their exact PIDs: terminate, then kill).  The caller
+    must not have initialised the GPU: children inherit nothing but the environment."""
+    script = os.path.abspath(__file__) if script is None else script
+    python = sys.executable if python is None else python
+    port = _free_port()
+    procs = [subprocess.Popen([python, script, *argv], env=rank_env(r, world, port), stdout=stdout, stderr=stderr)
+             for r in range(world)]
+
+    def end_all():
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.monotonic() + 10.0
+        for p in procs:
+            try:
+                p.wait(max(0.0, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+
+    t0 = time.monotonic()
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                r, c = bad[0]
+                print(f"bench.py launcher: rank {r} exited with status {c}; ending the other ranks", file=sys.stderr)
+                end_all()
+                return c if c > 0 else 128 - c
+            if all(c == 0 for c in codes):
+                return 0
+            if time.monotonic() - t0 > timeout:
+                print(f"bench.py launcher: ranks still running after {timeout:.0f} s; ending them", file=sys.stderr)
+                end_all()
+                return EXIT_TIMEOUT
+            time.sleep(poll_s)
+    except BaseException:
+        end_all()
+        raise
 
 
 def cpu_baseline(cfg, arrays, cam, n_rays):
@@ -192,26 +272,45 @@ def counted_tests(count_lib, scene, camera, depth):
             "waves": c[7], "tests_executed": c[0] * 64}
 
 
-def main():
-    args = parse()
+def main(argv=None) -> int:
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: be the launcher.  Nothing in this process has touched the
+        # GPU (torch is not imported yet); the ranks are fresh children, rank 0 prints the line.
+        return spawn_ranks(args.gpus, argv, timeout=args.launch_timeout)
+    return rank_main(args)
+
+
+def rank_main(args) -> int:
+    global np, torch, dist
+    import datetime
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run "
-                             "(--nproc-per-node N)")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     if args.same_device:
         local_rank = 0
+    elif world > 1 and torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} devices are visible "
+                         "(--same-device --backend gloo rehearses the N > 1 path on one)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
+        # a finite timeout: a missing rank or a hung collective ends the run non-zero instead of hanging it
+        tmo = datetime.timedelta(seconds=args.dist_timeout)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, timeout=tmo)
 
     import rtgs
     from rtgs import _native as nat
@@ -276,6 +375,16 @@ def main():
     ev1.record()
     torch.cuda.synchronize()
     project_ms = ev0.elapsed_time(ev1) / reps
+    # every rank's shard trace and projection (ms), so that imbalance between the ranks is visible
+    per_rank = None
+    if world > 1:
+        rows = [None] * world
+        dist.all_gather_object(rows, {"rank": rank, "local_tiles": renderer.local_tiles,
+                                      "trace_ms": trace_ms, "project_ms": project_ms})
+        per_rank = {"trace_ms": [r["trace_ms"] for r in rows], "project_ms": [r["project_ms"] for r in rows],
+                    "local_tiles": [r["local_tiles"] for r in rows]}
+        for k in ("trace_ms", "project_ms"):
+            per_rank[k + "_min"], per_rank[k + "_max"] = min(per_rank[k]), max(per_rank[k])
 
     # SURVEY 8(d) secondary figures: per-frame HIP-event times (median of 30 frames, first launch
     # to framebuffer complete) and closest-hit queries/s = depth x rays/s
@@ -420,12 +529,22 @@ def main():
             line["secondary"]["scene_hit_960x540"] = closest_hit_rates(scene, cam)
         if verified is not None:
             line["verified"] = verified
+        if per_rank is not None:
+            line["per_rank"] = per_rank
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, arrays, cam, args.cpu_rays)
         print(json.dumps(line), flush=True)
+    status = 0
     if world > 1:
+        # every rank leaves with the same status: an unverified run must not look like a measurement
+        flag = [verified if rank == 0 else None]
+        dist.broadcast_object_list(flag, src=0)
+        if flag[0] is not True:
+            print(f"bench.py rank {rank}: frames did not verify against the single-rank render", file=sys.stderr)
+            status = EXIT_UNVERIFIED
         dist.destroy_process_group()
+    return status
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RTGS_ABI_VERSION 5
+#define RTGS_ABI_VERSION 6
 #define RTGS_MAX_DEPTH 16        /* peels kept per ray in one pass (__main__.py:70 default) */
 #ifndef RTGS_TILE
 #define RTGS_TILE 16             /* macro-tile edge in pixels: one workgroup, the unit of sharding */
@@ -133,8 +133,12 @@ int rtgs_generate_rays(const RtgsCamera* cam, float* rays /*[W][H][8]*/, rtgs_st
 size_t rtgs_pose_bytes(void);
 int rtgs_pose_pack(const RtgsCamera* cam, void* host_out);
 
-/* Bytes of scratch rtgs_trace needs for n Gaussians (per-frame projected records). */
+/* Bytes of scratch rtgs_trace needs for n Gaussians (per-frame projected records, slab bounds, bins):
+ * rtgs_workspace_bytes is enough for a frame of ANY size (it provides 64 MiB for the macro-tiles' own
+ * slab lists), rtgs_workspace_bytes_frame (ABI v6) is what a width x height frame needs (8 MB of
+ * lists at 1080p, 33 MB at 4K).  The calls check against the frame's figure. */
 size_t rtgs_workspace_bytes(int32_t n);
+size_t rtgs_workspace_bytes_frame(int32_t n, int32_t width, int32_t height);
 
 /* Macro-tile edge the library was built with, the number of macro-tiles of a W x H image, and
  * how many of them a shard owns. */

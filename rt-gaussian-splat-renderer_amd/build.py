@@ -56,12 +56,19 @@ def _hip_deps():
     return srcs, srcs + [os.path.join(CSRC, "rtgs_common.hpp"), os.path.join(ROOT, "include", "rtgs_hip.h")]
 
 
-def _stamp_ok(target) -> bool:
-    """The library was built from exactly these sources (hash stamp beside it) -- mtimes alone say
-    nothing after a checkout or a snapshot copy."""
+def _stamp(extra_flags=()) -> str:
+    """What the stamp beside a library says: the source hash, and the extra compile flags when there
+    are any -- a -DRTGS_ABLATE / STAMPS / COUNT build must never pass for the product library."""
+    flags = " ".join(extra_flags)
+    return source_hash() + (" " + flags if flags else "")
+
+
+def _stamp_ok(target, extra_flags=()) -> bool:
+    """The library was built from exactly these sources WITH exactly these flags (stamp beside it)
+    -- mtimes alone say nothing after a checkout or a snapshot copy."""
     try:
         with open(target + ".srchash") as f:
-            return f.read().strip() == source_hash() and os.path.exists(target)
+            return f.read().strip() == _stamp(extra_flags) and os.path.exists(target)
     except OSError:
         return False
 
@@ -73,20 +80,21 @@ def _hipcc(out, extra_flags=()):
     _run([hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, *extra_flags, *srcs, "-o", out])
     with open(out + ".srchash", "w") as f:
-        f.write(source_hash() + "\n")
+        f.write(_stamp(extra_flags) + "\n")
 
 
 def build_hip(force: bool = False, extra_flags=()) -> str:
     """hipcc --offload-arch=gfx950 -> rtgs/_lib/librtgs_hip.so (cross-compiles without a GPU).
-    Skipped only when the source-hash stamp written by the last build matches the tree."""
-    if force or extra_flags or not _stamp_ok(LIB):
+    Skipped only when the stamp written by the last build matches the tree and the flags: after a
+    diagnostic build (extra_flags: tools/ab.sh and friends) the next plain build_hip() recompiles."""
+    if force or not _stamp_ok(LIB, extra_flags):
         _hipcc(LIB, extra_flags)
     return LIB
 
 
 def build_count(force: bool = False) -> str:
     """The counting variant (see COUNT_LIB)."""
-    if force or not _stamp_ok(COUNT_LIB):
+    if force or not _stamp_ok(COUNT_LIB, ["-DRTGS_COUNT=1"]):
         _hipcc(COUNT_LIB, ["-DRTGS_COUNT=1"])
     return COUNT_LIB
 

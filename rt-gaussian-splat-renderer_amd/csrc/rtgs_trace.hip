@@ -1771,14 +1771,15 @@ using namespace rtgs;
 
 extern "C" {
 
-// bins: [counts kBinSupertilesMax int][lists kBinSupertilesMax x bin_stride_of(nslabs) int], behind the depth keys
-static size_t bins_bytes(size_t nslabs) {
+// bins: [counts kBinSupertilesMax int][lists kBinSupertilesMax x bin_stride_of(nslabs) int], behind the depth keys,
+// + the macro-tiles' own lists, 1 KB per tile of the frame (8 MB at 1080p, 33 MB at 4K; frames of more than
+// kTileBinTilesMax tiles do without)
+static size_t bins_bytes(size_t nslabs, size_t tiles) {
 #if RTGS_BINS
-  // + the macro-tiles' own lists (64 MiB: 65 536 tiles x 1 KB -- an 8K x 4K frame; 2 % of it at 1080p)
   return (size_t)kBinSupertilesMax * sizeof(int32_t) * (1 + (size_t)bin_stride_of(nslabs)) +
-         (RTGS_TILE_BINS ? (size_t)kTileBinTilesMax * kTileBinCap * sizeof(int32_t) : 0);
+         (RTGS_TILE_BINS && tiles <= (size_t)kTileBinTilesMax ? tiles * kTileBinCap * sizeof(int32_t) : 0);
 #else
-  (void)nslabs;
+  (void)nslabs; (void)tiles;
   return 0;
 #endif
 }
@@ -1803,12 +1804,21 @@ static BinGeom bin_geom(int width, int height) {
   }
 }
 
-size_t rtgs_workspace_bytes(int32_t n) {
+static size_t workspace_bytes_tiles(int32_t n, size_t tiles) {
   if (n <= 0) return 0;
   const size_t nn = ((size_t)n + 63) & ~(size_t)63;
   const size_t nslabs = nn / kSlab, nsuper = (nslabs + kSuper - 1) / kSuper;
   return nn * sizeof(float4) + nn * (kRecFloats + kTailFloats + 1) * sizeof(float) + (nslabs + nsuper) * sizeof(float4) +
-         ((nslabs + 3) & ~(size_t)3) * sizeof(float) + bins_bytes(nslabs);
+         ((nslabs + 3) & ~(size_t)3) * sizeof(float) + bins_bytes(nslabs, tiles);
+}
+
+// any frame size: provides for kTileBinTilesMax tiles (64 MiB of per-tile lists)
+size_t rtgs_workspace_bytes(int32_t n) { return workspace_bytes_tiles(n, (size_t)kTileBinTilesMax); }
+
+// what a width x height frame needs (ABI v6): the per-tile lists sized from the frame
+size_t rtgs_workspace_bytes_frame(int32_t n, int32_t width, int32_t height) {
+  if (width <= 0 || height <= 0) return 0;
+  return workspace_bytes_tiles(n, (size_t)((width + kTile - 1) / kTile) * (size_t)((height + kTile - 1) / kTile));
 }
 
 size_t rtgs_pose_bytes(void) { return sizeof(FrameCam); }
@@ -1884,7 +1894,7 @@ static int validate(const RtgsScene* scene, const RtgsCamera* cam, void* ws, siz
     return RTGS_EINVAL;
   if (scene->n > kMaxGaussians) return RTGS_EINVAL;   // 32-bit record offsets, index << 4 | slot payloads
   if (cam->width <= 0 || cam->height <= 0 || !(cam->fx > 0.f) || !(cam->fy > 0.f)) return RTGS_EINVAL;
-  if (ws_bytes < rtgs_workspace_bytes(scene->n)) return RTGS_EWORKSPACE;
+  if (ws_bytes < rtgs_workspace_bytes_frame(scene->n, cam->width, cam->height)) return RTGS_EWORKSPACE;
   if (reinterpret_cast<uintptr_t>(ws) & 15u) return RTGS_EINVAL;
   return RTGS_OK;
 }

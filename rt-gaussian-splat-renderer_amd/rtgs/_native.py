@@ -14,7 +14,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_size_t, c_u
 
 import torch  # noqa: F401  (must precede the CDLL load, see module docstring)
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_DEPTH = 16
 RAY_FLOATS = 8
 SH_COEFFS = 15
@@ -51,6 +51,7 @@ PROTOTYPES = {
     "rtgs_covariance": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rtgs_generate_rays": (c_int32, [POINTER(RtgsCamera), c_void_p, c_void_p]),
     "rtgs_workspace_bytes": (c_size_t, [c_int32]),
+    "rtgs_workspace_bytes_frame": (c_size_t, [c_int32, c_int32, c_int32]),
     "rtgs_pose_bytes": (c_size_t, []),
     "rtgs_pose_pack": (c_int32, [POINTER(RtgsCamera), c_void_p]),
     "rtgs_tile_size": (c_int32, []),

@@ -49,7 +49,11 @@ class Camera:
         return ray
 
     def generate_ray_field(self, position, rotation) -> None:
-        """Fill ``cam_ray_field`` with one ray per pixel centre (camera.py:57-71)."""
+        """Fill ``cam_ray_field`` with one ray per pixel centre (camera.py:57-71).  A deferred update
+        that also owes per-pixel STATE (``RayTracer.sample_all``: the attenuation buffer lives in the
+        tracer, not in this field) settles that part first (``RayField.supersede``) -- regenerating the
+        rays supersedes the ``.start`` column, not the attenuation the eager calls would have left."""
+        self.cam_ray_field.supersede()
         self._generate(position, rotation)
         self.cam_ray_field.defer(None, False)      # up to date; supersedes any deferred update
         self.field_position = vec3(position)
@@ -60,10 +64,10 @@ class Camera:
         nat.check(nat.lib().rtgs_generate_rays(cam, nat.ptr(self.cam_ray_field.storage), nat.stream()),
                   "rtgs_generate_rays")
 
-    def defer_ray_field(self, position, rotation, update, state_deferred: bool) -> None:
+    def defer_ray_field(self, position, rotation, update, state_deferred: bool, superseded=None) -> None:
         """What ``RayTracer`` calls instead of ``generate_ray_field`` at the start of a sample: the
         field *logically* holds the rays of this pose from now on, but its 32 B per pixel are only
         rewritten (by ``update``) when somebody reads or edits it (``RayField`` docstring)."""
-        self.cam_ray_field.defer(update, state_deferred)
+        self.cam_ray_field.defer(update, state_deferred, superseded)
         self.field_position = vec3(position)
         self.field_rotation = vec4(rotation)

@@ -74,7 +74,7 @@ class HipBackend:
         self.device = nat.device()
         self.width, self.height = camera.buf_size.x, camera.buf_size.y
         self.tile = nat.tile_size()
-        need = nat.lib().rtgs_workspace_bytes(scene.num_gaussians)
+        need = nat.lib().rtgs_workspace_bytes_frame(scene.num_gaussians, self.width, self.height)
         self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
         self._orders = {}
         self._state = {}
@@ -143,8 +143,13 @@ class HipBackend:
         if self.depth > nat.MAX_DEPTH:
             # a chain of launches through per-pixel state (rtgs_hip.h, RtgsTraceParams.depth): one
             # (attenuation, ray.start) pair per workspace, i.e. per frame in flight
-            att, start = self._state.setdefault(ws.data_ptr(), (self.alloc(self.width, self.height),
-                                                                 self.alloc(self.width, self.height)))
+            pair = self._state.get(ws.data_ptr())
+            if pair is None:
+                pair = self._state[ws.data_ptr()] = (self.alloc(self.width, self.height),
+                                                     self.alloc(self.width, self.height))
+                if stream is not None:   # the zero-fills ran on the current stream: order the first use after them
+                    stream.wait_stream(nat.current_stream(self.device.index))
+            att, start = pair
         nat.check(nat.lib().rtgs_trace(self.scene.native(), self.camera.native(), params,
                                        nat.ptr(out), nat.ptr(att), nat.ptr(start), 1, nat.ptr(ws), ws.numel(),
                                        1 if projected else 0, st),
@@ -376,10 +381,7 @@ class TileParallelRenderer:
     def _scene_key(self):
         """Changes when work queued on the CALLER's stream may have written what the render streams
         read: a re-commit, or an in-place edit of a streamed tensor (torch bumps ``_version``)."""
-        sc = self.backend.scene
-        sh = sc.sh
-        return (sc.version, sc.position._version, sc.rotation._version, sc.scale._version,
-                sc.color_opacity._version, -1 if sh is None else sh._version)
+        return self.backend.scene.content_key()
 
     def render_frame(self) -> None:
         """Queue one frame.  world == 1: straight into ``framebuffer``.  world > 1: trace this

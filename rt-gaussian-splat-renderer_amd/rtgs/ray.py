@@ -88,6 +88,7 @@ class RayField:
         self._edited = True     # not (yet) a generated camera ray field
         self._clean_version = self._data._version
         self._pending = None    # deferred update: callable that brings the tensor up to date
+        self._pending_superseded = None   # what is left of that update when the rays are regenerated anyway
         self.state_deferred = False   # the deferred update also owes the .start column (and the tracer's attenuation)
 
     # ---- deferred updates -----------------------------------------------------------------
@@ -103,7 +104,7 @@ class RayField:
 
     @data.setter
     def data(self, value: torch.Tensor) -> None:
-        self._pending, self.state_deferred = None, False
+        self._pending, self._pending_superseded, self.state_deferred = None, None, False
         self._data = nat.require_device(value, "ray field")
         self.mark_edited(True)
 
@@ -111,17 +112,34 @@ class RayField:
     def pending(self) -> bool:
         return self._pending is not None
 
-    def defer(self, update, state_deferred: bool) -> None:
+    def defer(self, update, state_deferred: bool, superseded=None) -> None:
         """Replace whatever update was pending by `update` (a whole-field regeneration supersedes
-        any earlier one) and mark the field clean: its *logical* contents are generated rays."""
+        any earlier one) and mark the field clean: its *logical* contents are generated rays.
+        `superseded`: what remains to be done of `update` if the rays are regenerated before anybody
+        looked (state that lives OUTSIDE this field: the tracer's attenuation buffer)."""
         self._pending, self.state_deferred = update, bool(state_deferred)
+        self._pending_superseded = superseded if update is not None else None
         self.mark_edited(False)
 
     def materialise(self) -> None:
         if self._pending is not None:
-            update, self._pending, self.state_deferred = self._pending, None, False
-            update()
+            saved = (self._pending, self._pending_superseded, self.state_deferred)
+            self._pending, self._pending_superseded, self.state_deferred = None, None, False
+            try:
+                saved[0]()
+            except BaseException:
+                # the debt stands (a reader keeps being told) until a new sample or regeneration replaces it
+                self._pending, self._pending_superseded, self.state_deferred = saved
+                raise
             self.mark_edited(False)   # the update wrote through torch / raw pointers: still generated rays
+
+    def supersede(self) -> None:
+        """The rays are about to be regenerated: drop the pending update, after settling the part of
+        it that does not live in this field (``defer``'s `superseded`)."""
+        rest = self._pending_superseded
+        if self._pending is not None and rest is not None:
+            rest()
+        self._pending, self._pending_superseded, self.state_deferred = None, None, False
 
     @property
     def edited(self) -> bool:

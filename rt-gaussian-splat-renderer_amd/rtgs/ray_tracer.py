@@ -40,6 +40,7 @@ class RayTracer:
         self._orders = {}            # (tile_first, tile_step) -> device int32 launch order
         # RTGS_TILE_ORDER as in parallel.HipBackend: 0 = tile order, centre, wedge (default)
         self._order_mode = os.environ.get("RTGS_TILE_ORDER", "wedge")
+        self._att_cleared = False    # clear_attenuation() ran while sample_all's per-pixel state was still owed
 
     @property
     def attenuation_buf(self) -> torch.Tensor:
@@ -52,7 +53,7 @@ class RayTracer:
 
     # ---- plumbing ------------------------------------------------------------------------
     def _ws(self) -> torch.Tensor:
-        need = nat.lib().rtgs_workspace_bytes(self.scene.num_gaussians)
+        need = nat.lib().rtgs_workspace_bytes_frame(self.scene.num_gaussians, self.buf_size.x, self.buf_size.y)
         if self._workspace is None or self._workspace.numel() < need:
             self._workspace = torch.empty(need, dtype=torch.uint8, device=self.sample_buf.device)
         return self._workspace
@@ -112,13 +113,32 @@ class RayTracer:
         self.camera._generate(pos, rot)
         f.storage[..., 6] = keep
 
-    def _replay_state(self, pos, rot, depth: int, t_cutoff: float) -> None:
+    def _state_key(self):
+        """Everything besides the pose that the per-pixel state of a sample depends on."""
+        return (id(self.scene), self.scene.content_key(), tuple(float(v) for v in self.camera.focal_length))
+
+    def _replay_state(self, pos, rot, depth: int, t_cutoff: float, key, rays_superseded: bool = False) -> None:
         """Deferred update after ``sample_all``: generated rays of that pose, then the per-pixel
         state (``.start``, attenuation) the ``depth`` peels leave, by tracing once more into a
-        scratch image."""
+        scratch image.  Only the scene and focal length the sample was taken with can give that
+        state back: if either changed in between, the state of that sample is gone and saying so
+        beats handing out the state of a frame that was never rendered.  `rays_superseded`: the rays
+        are being regenerated anyway (``Camera.generate_ray_field``), only the attenuation is still owed
+        -- and not even that once ``clear_attenuation()`` has run."""
+        if rays_superseded and self._att_cleared:
+            self._att_cleared = False
+            return
+        if key != self._state_key():
+            raise RuntimeError(
+                "the scene (or focal length) changed after sample_all(): the per-pixel state of that sample "
+                "(attenuation_buf, cam_ray_field.start) can no longer be reconstructed.  Read it before "
+                "editing the scene, or take the sample with sample_all(..., lazy_state=False)")
         self.camera._generate(pos, rot)
         scratch = torch.empty_like(self.sample_buf)
         self.trace(depth, t_cutoff=t_cutoff, sample_buf=scratch, position=pos, rotation=rot)
+        if self._att_cleared:          # the caller has cleared the attenuation since: ones are what it holds
+            self._att_cleared = False
+            self.clear_attenuation()
 
     # ---- the reference's API ------------------------------------------------------------
     def sample(self, depth: int):
@@ -166,20 +186,25 @@ class RayTracer:
                                                         nat.ptr(self.sample_buf), nat.ptr(self._attenuation),
                                                         nat.stream()), "rtgs_sample_step_rays")
 
-    def sample_all(self, depth: int, t_cutoff: float = 0.0):
+    def sample_all(self, depth: int, t_cutoff: float = 0.0, lazy_state: bool = True):
         """Extension: one WHOLE sample (``depth`` peels) in a single call -- the result of
         calling ``sample(depth)`` ``depth`` times from num_steps == 0.  Any depth: above
         ``RTGS_MAX_DEPTH`` (16) the library chains ceil(depth / 16) launches through the per-pixel
         state (the reference's ``-d`` is unbounded, __main__.py:66-71).  Up to 16 the state
         (``attenuation_buf``, ``cam_ray_field``) is not written at all unless somebody reads it
-        afterwards: the frame costs what the tile-parallel path's does."""
+        afterwards: the frame costs what the tile-parallel path's does.  The deferred state is that of
+        THIS scene and focal length: editing either before the state is read makes the read raise
+        (``lazy_state=False`` writes it with the sample, 90 MB more traffic per 1080p frame)."""
         if self.num_steps != 0:
             raise RuntimeError("sample_all() needs num_steps == 0 (finish the partial sample first)")
         depth = int(depth)
         pos, rot = self._pose()
-        if depth <= nat.MAX_DEPTH:
+        self._att_cleared = False
+        if depth <= nat.MAX_DEPTH and lazy_state:
             self.trace(depth, flags=nat.TRACE_ACCUMULATE, t_cutoff=t_cutoff, state=False)
-            self.camera.defer_ray_field(pos, rot, lambda: self._replay_state(pos, rot, depth, t_cutoff), True)
+            key = self._state_key()
+            self.camera.defer_ray_field(pos, rot, lambda: self._replay_state(pos, rot, depth, t_cutoff, key), True,
+                                        lambda: self._replay_state(pos, rot, depth, t_cutoff, key, True))
         else:
             self.trace(depth, flags=nat.TRACE_ACCUMULATE, t_cutoff=t_cutoff)
             self.camera.defer_ray_field(pos, rot, lambda: self._regenerate_keeping_start(pos, rot), False)
@@ -191,7 +216,11 @@ class RayTracer:
                                       nat.stream()), "rtgs_fill")
 
     def clear_attenuation(self):
-        """ray_tracer.py:62-66."""
+        """ray_tracer.py:62-66.  While ``sample_all``'s per-pixel state is still owed, the attenuation
+        part of that debt is cancelled: the replay ends by filling ones again."""
+        f = self.camera.cam_ray_field
+        if f.pending and f.state_deferred:
+            self._att_cleared = True
         nat.check(nat.lib().rtgs_fill(nat.ptr(self._attenuation), self._attenuation.numel(),
                                       1.0, nat.stream()), "rtgs_fill")
 

@@ -252,6 +252,11 @@ class Scene:
         torch ``_version``.  Everything cached from the geometry (projections, ``accel``) is keyed on it."""
         return (self.version, self.position._version, self.rotation._version, self.scale._version)
 
+    def content_key(self) -> tuple:
+        """``geometry_key`` plus the shading tensors (colour / opacity, SH): changes whenever anything a
+        rendered pixel depends on may have.  What deferred per-pixel state is keyed on."""
+        return self.geometry_key() + (self.color_opacity._version, -1 if self.sh is None else self.sh._version)
+
     def accel(self) -> torch.Tensor:
         """The structure that stands in for the reference's BVH on arbitrary-ray queries
         (scene.py:162-404 builds it in ``load_file``; here it is built on first use, after every

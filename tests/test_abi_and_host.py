@@ -34,12 +34,18 @@ def test_library_exports_every_declared_symbol():
 def test_pure_host_entry_points():
     from rtgs import _native as nat
     lib = nat.lib()
-    assert lib.rtgs_abi_version() == nat.ABI_VERSION == 5
+    assert lib.rtgs_abi_version() == nat.ABI_VERSION == 6
     assert lib.rtgs_strerror(0) == b"ok"
     for code in (-1, -2, -3, -4, -5, -99):
         assert len(lib.rtgs_strerror(code)) > 0
     assert lib.rtgs_workspace_bytes(0) == 0 and lib.rtgs_workspace_bytes(-5) == 0
     assert lib.rtgs_workspace_bytes(100_000) >= 100_000 * 96
+    # the frame-sized figure (ABI v6): 1 KB of per-tile slab list per macro-tile instead of 64 MiB for any frame
+    full, hd, uhd = (lib.rtgs_workspace_bytes(100_000), lib.rtgs_workspace_bytes_frame(100_000, 1920, 1080),
+                     lib.rtgs_workspace_bytes_frame(100_000, 3840, 2160))
+    assert full - hd == (65536 - 120 * 68) * 1024 and uhd - hd == (240 * 135 - 120 * 68) * 1024
+    assert lib.rtgs_workspace_bytes_frame(100_000, 0, 5) == 0 and lib.rtgs_workspace_bytes_frame(0, 64, 64) == 0
+    assert lib.rtgs_workspace_bytes_frame(100_000, 16 * 4096, 16 * 17) < hd       # too many tiles: no per-tile lists
     t = lib.rtgs_tile_size()
     assert t in (8, 16, 32) and t == nat.tile_size()
     assert lib.rtgs_num_tiles(1920, 1080) == -(-1920 // t) * -(-1080 // t)
@@ -239,4 +245,9 @@ def test_build_is_keyed_on_the_source_hash_not_on_mtimes(tmp_path):
     assert not b._stamp_ok(str(lib))                         # another tree's stamp: rebuild
     (tmp_path / "lib.so.srchash").write_text(b.source_hash() + "\n")
     assert b._stamp_ok(str(lib))
-    assert b._stamp_ok(b.LIB) and b._stamp_ok(b.COUNT_LIB)   # what build() left in the tree is current
+    # the flags are part of the stamp -- a diagnostic build must not pass for the product library
+    assert not b._stamp_ok(str(lib), ["-DRTGS_ABLATE=1"])
+    (tmp_path / "lib.so.srchash").write_text(b._stamp(["-DRTGS_ABLATE=1"]) + "\n")
+    assert b._stamp_ok(str(lib), ["-DRTGS_ABLATE=1"]) and not b._stamp_ok(str(lib))
+    # what build() left in the tree is current: the product library without flags, the counting build with its own
+    assert b._stamp_ok(b.LIB) and b._stamp_ok(b.COUNT_LIB, ["-DRTGS_COUNT=1"]) and not b._stamp_ok(b.COUNT_LIB)

@@ -1,0 +1,55 @@
+"""bench.py as the driver runs it for N > 1: a bare `python bench.py --gpus N` that starts its own
+ranks.  On a one-GPU box the ranks share cuda:0 and talk over gloo -- everything of
+the frame loop except RCCL itself: F render streams, rtgs_shard_frame / rtgs_frames_land, the
+gather, the per-rank statistics, the verification against the single-rank render, the exit status."""
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _run(args, env=None, timeout=900):
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None)
+    e.pop("RANK", None)
+    e.update(env or {})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                         timeout=timeout, env=e, cwd=ROOT)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    return out, (json.loads(lines[-1]) if lines else None)
+
+
+@pytest.mark.parametrize("env", [{}, {"RTGS_GATHER_BATCH": "2", "RTGS_FRAMES_IN_FLIGHT": "3"}])
+def test_bare_bench_with_two_ranks_starts_them_itself_and_verifies(env):
+    out, line = _run(["--gpus", "2", "--backend", "gloo", "--same-device", "--steps", "6", "--warmup", "2",
+                      "--config", "c2"], env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert line is not None and line["n_gpus"] == 2 and line["verified"] is True
+    assert line["value"] > 0 and line["steps"] == 6
+    pr = line["per_rank"]
+    assert len(pr["trace_ms"]) == 2 and pr["trace_ms_min"] <= pr["trace_ms_max"]
+    assert sum(pr["local_tiles"]) == -(-800 // 16) * -(-600 // 16)
+    assert "gloo" in line["config"]["parallelism"]            # a rehearsal must say so
+
+
+def test_more_ranks_than_devices_is_refused_with_a_nonzero_status():
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a one-GPU box")
+    out, line = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "c2"])
+    assert out.returncode != 0 and line is None
+    assert "devices are visible" in out.stderr
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
+@pytest.mark.parametrize("env", [{}, {"RTGS_GATHER_BATCH": "2"}])
+def test_two_ranks_over_rccl(env):
+    out, line = _run(["--gpus", "2", "--steps", "20", "--warmup", "5", "--config", "c2"], env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert line["verified"] is True and "RCCL" in line["config"]["parallelism"]

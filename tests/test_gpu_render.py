@@ -354,6 +354,51 @@ def test_sample_all_defers_the_per_pixel_state_until_somebody_looks():
     assert float((a.sample_buf - b.sample_buf).abs().max()) <= 6e-6 and not torch.equal(b.sample_buf, b_extra)
 
 
+def test_deferred_state_keeps_the_eager_calls_promise_through_clears_regeneration_and_scene_edits():
+    # ADVICE r3 (medium) / VERDICT r3 #7: what a reader sees after sample_all must be what the eager
+    # calls (ray_tracer.py:39-66) would have left, whatever is called in between
+    arrays, cam, depth = U.case("shallow")
+    scene, camera, a = U.build(arrays, cam)
+    _, camera_b, b = U.build(arrays, cam)
+    for _ in range(depth):
+        b.sample(depth)                                   # eager twin: state after one whole sample
+    want_att, want_start = b.attenuation_buf.clone(), camera_b.cam_ray_field.start.clone()
+    assert float((want_att - 1).abs().max()) > 0.1
+    # (1) sample_all -> clear_attenuation -> read: ones (ray_tracer.py:62-66), and .start is still the sample's
+    a.sample_all(depth)
+    a.clear_attenuation()
+    assert torch.equal(a.attenuation_buf, torch.ones_like(want_att))
+    s = camera.cam_ray_field.start
+    assert torch.equal(torch.isfinite(s), torch.isfinite(want_start)) and torch.equal(s[torch.isfinite(s)], want_start[torch.isfinite(want_start)])
+    assert torch.equal(a.attenuation_buf, torch.ones_like(want_att))          # ... and stays ones
+    # (2) sample_all -> generate_ray_field -> attenuation_buf: the sample's attenuation, rays regenerated (start 0)
+    a.sample_all(depth)
+    camera.generate_ray_field(camera.position, camera.rotation)
+    assert float((a.attenuation_buf - want_att).abs().max()) <= 2e-6
+    assert float(camera.cam_ray_field.start.abs().max()) == 0.0
+    # (3) a scene edit between sample_all and the read: the state of that sample is gone -- say so
+    a.sample_all(depth)
+    scene.color_opacity[:, 3].mul_(0.5)
+    with pytest.raises(RuntimeError, match="changed after sample_all"):
+        a.attenuation_buf
+    with pytest.raises(RuntimeError, match="changed after sample_all"):
+        a.sample_step()
+    with pytest.raises(RuntimeError, match="changed after sample_all"):
+        camera.generate_ray_field(camera.position, camera.rotation)      # would owe the attenuation
+    # the reference's start-of-sample pair (ray_tracer.py:46-49) cancels both halves of the debt
+    a.clear_attenuation()
+    camera.generate_ray_field(camera.position, camera.rotation)
+    assert torch.equal(a.attenuation_buf, torch.ones_like(want_att)) and not camera.cam_ray_field.pending
+    a.sample_all(depth)                                   # a new sample supersedes any debt
+    half = a.attenuation_buf.clone()
+    assert float((half - want_att).abs().max()) > 0.05    # state of the EDITED scene
+    scene.position.add_(0.0)                               # geometry version bump
+    a.sample_all(depth, lazy_state=False)                  # eager: nothing owed, edits afterwards are harmless
+    scene.color_opacity[:, 3].mul_(2.0)
+    assert float((a.attenuation_buf - half).abs().max()) <= 2e-6
+    assert not camera.cam_ray_field.state_deferred
+
+
 # ---- edited ray fields: the literal per-ray sample_step (ray_tracer.py:79-104) ----
 
 def _edited_field_case(sh):
