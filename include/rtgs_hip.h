@@ -168,13 +168,12 @@ int32_t rtgs_launch_order(int32_t width, int32_t height, int32_t tile_first, int
  *   ray_start        &rays[0][0][6] with stride 8 floats, i.e. cam_ray_field[i,j].start,
  *                    in (RESUME) / out (t1 of the last peel + 1e-8, or +inf after a miss);
  *                    may be NULL without RESUME and depth <= RTGS_MAX_DEPTH.  Exact fp32 ties in
- *                    t1 (the reference composites one of them, scene.py:433 after
- *                    ray_tracer.py:101) each take one of the 16 list slots of a launch: a pixel
- *                    with such a tie among its 16 nearest composites 15 distinct entries per
- *                    launch instead of 16 (a few dozen pixels of a 1080p frame; at smaller depths
- *                    the launch walks on through its slots) and resumes behind the list's last
- *                    entry, so a chain loses no Gaussian, only that pixel's last peel.  ray_start_stride in floats (8 for a Ray
- *                    field, 1 for a plain [W][H] plane).
+ *                    t1: one of the tied Gaussians is composited, as in the reference (scene.py:433
+ *                    strict `>` after ray_tracer.py:101), and `depth` DISTINCT entry distances
+ *                    are composited whatever the ties -- a tied twin takes one of the 16 list slots
+ *                    of a launch, and the (rare) ray whose list came up short that way peels on
+ *                    inside the kernel (ABI v6; up to v5 such a pixel lost its last peel).
+ *                    ray_start_stride in floats (8 for a Ray field, 1 for a plain [W][H] plane).
  * Runs the per-frame projection (rtgs_project) first unless `projected` is non-zero. */
 int rtgs_trace(const RtgsScene* scene, const RtgsCamera* cam, const RtgsTraceParams* params,
                float* sample_buf, float* attenuation_buf, float* ray_start,
@@ -201,6 +200,30 @@ int rtgs_project_shard(const RtgsScene* scene, const RtgsCamera* cam, int32_t ti
 int rtgs_render(const RtgsScene* scene, const RtgsCamera* cam, int32_t depth, float t_cutoff,
                 int32_t tile_y0, int32_t tile_y1, float* sample_out, float* transmittance_out,
                 void* workspace, size_t workspace_bytes, rtgs_stream_t stream);
+
+/* ---- peel lists (ABI v6) ----
+ * The reference's viewer takes a sample as `depth` calls of RayTracer.sample (__main__.py:253-256), each
+ * one peel (ray_tracer.py:39-54) that re-walks the scene for every pixel.  These three serve that call
+ * pattern from ONE traversal: rtgs_trace_lists runs rtgs_trace's pass for the whole frame but, instead
+ * of compositing, stores every ray's sorted DISTINCT entries (up to RTGS_MAX_DEPTH of them: Gaussian
+ * index, exponent, t1) in `lists` (rtgs_peel_list_bytes(W, H) bytes, 16-B aligned, caller-owned;
+ * 192 B per pixel); rtgs_peel composites entry k of every ray -- sample_buf += attenuation * alpha *
+ * colour, attenuation *= 1 - alpha, exactly sample_step's update -- reading colours / opacities / SH
+ * from the scene at call time; rtgs_peel_start writes the ray.start the first `peels_done` peels imply
+ * (t1 of the last + 1e-8, +inf after a miss, 0 for none).  The lists depend on the Gaussians' geometry
+ * and the camera only: they stay valid across samples while neither changes.
+ *   flags of rtgs_peel: RTGS_PEEL_FRESH = the sample starts with this peel (attenuation 1 instead of the
+ *   buffer's contents: the clear_attenuation of ray_tracer.py:46). */
+#define RTGS_PEEL_FRESH 1u
+size_t rtgs_peel_list_bytes(int32_t width, int32_t height);
+int rtgs_trace_lists(const RtgsScene* scene, const RtgsCamera* cam, const int32_t* tile_order /*optional, as RtgsTraceParams*/,
+                     void* lists, size_t lists_bytes, void* workspace, size_t workspace_bytes, int32_t projected,
+                     rtgs_stream_t stream);
+int rtgs_peel(const RtgsScene* scene, const RtgsCamera* cam, const void* lists, size_t lists_bytes, int32_t k,
+              uint32_t flags, float* sample_buf /*[W][H][3] in/out*/, float* attenuation_buf /*[W][H] in/out*/,
+              rtgs_stream_t stream);
+int rtgs_peel_start(const RtgsCamera* cam, const void* lists, size_t lists_bytes, int32_t peels_done,
+                    float* ray_start, int32_t ray_start_stride, rtgs_stream_t stream);
 
 /* Tile-parallel epilogue: scatter gathered shard-compact buffers
  * compact[rank][local_tile][T][T][3], T = rtgs_tile_size(), (rank-major, `tiles_per_rank` tiles each, as produced

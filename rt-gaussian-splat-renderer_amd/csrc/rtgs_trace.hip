@@ -91,9 +91,6 @@ namespace {
 #ifndef RTGS_COUNT
 #define RTGS_COUNT 0      // counting build (librtgs_hip_count.so, bench.py's honesty columns): every wave adds its
 #endif                    // candidate / hit / insertion counts to device counters read by rtgs_debug_counters()
-#ifndef RTGS_ABLATE_PAYLOAD
-#define RTGS_ABLATE_PAYLOAD 0
-#endif
 #ifndef RTGS_ABLATE
 #define RTGS_ABLATE 0     // timing-only builds (wrong images): 1 no insertion, 2 no hit path,
 #endif                    // 3 no per-candidate loop, 4 no slab expansion either
@@ -113,15 +110,6 @@ namespace {
 #ifndef RTGS_CUT_TRAVERSAL
 #define RTGS_CUT_TRAVERSAL 1   // t_cutoff > 0 also ends a tile's traversal (k_trace<..., kCut = true>)
 #endif
-#ifndef RTGS_COMPOSITE_EXIT
-#define RTGS_COMPOSITE_EXIT 1
-#endif
-#ifndef RTGS_MED3
-#define RTGS_MED3 1   // keys move by v_med3_u32 (the list is sorted): 16 instead of 32 selects; c3 0.1506 -> 0.1388 ms
-#endif
-#ifndef RTGS_SKIP_LOWER
-#define RTGS_SKIP_LOWER 1   // skip the insertion's lower half when no lane inserts there
-#endif
 #ifndef RTGS_BINS
 #define RTGS_BINS 1       // per-frame supertile bins of depth-sorted slab lists (k_bin); 0: every tile scans all slab bounds
 #endif
@@ -129,11 +117,8 @@ namespace {
 #define RTGS_HORIZON 1    // chunk-level horizon test against the per-Gaussian distance bound (see k_trace)
 #endif
 #ifndef RTGS_TIER
-#define RTGS_TIER 8       // insertions touch only the first RTGS_TIER slots while slot RTGS_TIER-1 is empty in every lane (0: off)
-#endif
-#ifndef RTGS_FAST_DIV
-#define RTGS_FAST_DIV 1   // v_rcp_f32 / v_sqrt_f32 (1 ulp) instead of IEEE division / sqrt
-#endif
+#define RTGS_TIER 8       // insertions touch only the first RTGS_TIER slots while slot RTGS_TIER-1 is empty in every lane
+#endif                    // (best of 4 / 6 / 8 / 10 / 12; without the tiers c3 0.1634 -> 0.1545 ms)
 
 #ifndef RTGS_SLAB_ITERS
 #define RTGS_SLAB_ITERS 2
@@ -198,9 +183,6 @@ constexpr int kBigSceneSlabs = RTGS_BIG_SLABS;   // scenes with more slabs than 
 #define RTGS_SPLIT_MAX_TILES 700
 #endif
 constexpr int kSplitMaxTiles = RTGS_SPLIT_MAX_TILES;
-#ifndef RTGS_TWO_LEVEL
-#define RTGS_TWO_LEVEL 0   // 1: small scenes scan slab bounds in two levels too (c3: k_trace 0.260 vs
-#endif                      // 0.261 ms, but + 3 us for the k_super_bbox launch: no gain)
 #ifndef RTGS_SUPER
 #define RTGS_SUPER 16
 #endif
@@ -252,6 +234,11 @@ struct TraceArgs {
   const int32_t* bin_list;    // [supertiles][bin_stride]
   int32_t bin_stride, bin_shift, bin_sx;
   const int32_t* tile_bin;    // [tiles][kTileBinCap] or NULL: per-macro-tile lists, valid where the supertile's bin is
+  // peel lists (rtgs_trace_lists) or NULL: instead of compositing, the launch stores every pixel's sorted DISTINCT
+  // entries -- [tile][RTGS_MAX_DEPTH][256 threads] Gaussian index (-1 = no such entry), exponent, t1 -- for rtgs_peel
+  int32_t* list_idx;
+  float* list_w;
+  float* list_t;
 };
 
 #if RTGS_COUNT
@@ -265,12 +252,17 @@ __device__ unsigned long long g_count[8];
 // per-frame projection
 // ------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void k_project(int32_t n, const float* __restrict__ pos,
+// kThreads = 256, or 1024 for scenes whose slab bounds are scanned in two levels (Tune<true>): a block is then
+// exactly one group of kSuper = 16 slabs and writes the group's union bound itself (round 3 launched
+// k_super_bbox for that: 5.2 us of c5's prologue)
+template <int kThreads>
+__global__ __launch_bounds__(kThreads) void k_project(int32_t n, const float* __restrict__ pos,
                                                   const float* __restrict__ rot,
                                                   const float* __restrict__ scale, FrameCam cam,
                                                   const FrameCam* __restrict__ pose,
                                                   float4* __restrict__ bbox,
                                                   float4* __restrict__ slab_bbox,
+                                                  float4* __restrict__ super_bbox,
                                                   float* __restrict__ slab_key,
                                                   float* __restrict__ rec, float* __restrict__ tail,
                                                   float* __restrict__ tmin, int32_t* __restrict__ bin_reset) {
@@ -514,24 +506,23 @@ __global__ __launch_bounds__(256) void k_project(int32_t n, const float* __restr
     slab_bbox[g0 / kSlab] = bb;
     slab_key[g0 / kSlab] = d2;
   }
-}
-
-// Union bounds of kSuper consecutive slabs (big scenes only; see kSuper).
-__global__ __launch_bounds__(256) void k_super_bbox(int32_t nslabs, const float4* __restrict__ slab_bbox,
-                                                     float4* __restrict__ super_bbox) {
-  const int u = blockIdx.x * blockDim.x + threadIdx.x;
-  if (u * kSuper >= nslabs) return;
-  float4 bb = make_float4(kInf, kInf, -kInf, -kInf);
+  if constexpr (kThreads == kSuper * kSlab) {
+    // union bound of the block's kSuper slabs (slabs past the end contribute nothing)
+    __shared__ float4 s_sb[kSuper];
+    if ((threadIdx.x & (kWave - 1)) == 0) s_sb[threadIdx.x / kWave] = live ? bb : make_float4(kInf, kInf, -kInf, -kInf);
+    __syncthreads();
+    if (threadIdx.x < kWave) {
+      float4 u = threadIdx.x < kSuper ? s_sb[threadIdx.x] : make_float4(kInf, kInf, -kInf, -kInf);
 #pragma unroll
-  for (int k = 0; k < kSuper; ++k) {
-    const int sl = u * kSuper + k;
-    if (sl < nslabs) {
-      const float4 b = slab_bbox[sl];
-      bb.x = fminf(bb.x, b.x); bb.y = fminf(bb.y, b.y);
-      bb.z = fmaxf(bb.z, b.z); bb.w = fmaxf(bb.w, b.w);
+      for (int off = kSuper / 2; off > 0; off >>= 1) {
+        u.x = fminf(u.x, __shfl_xor(u.x, off));
+        u.y = fminf(u.y, __shfl_xor(u.y, off));
+        u.z = fmaxf(u.z, __shfl_xor(u.z, off));
+        u.w = fmaxf(u.w, __shfl_xor(u.w, off));
+      }
+      if (threadIdx.x == 0) super_bbox[blockIdx.x] = u;
     }
   }
-  super_bbox[u] = bb;
 }
 
 // ------------------------------------------------------------------------------------
@@ -569,8 +560,8 @@ __global__ __launch_bounds__(256) void k_bin(int32_t nslabs, const float4* __res
                                               int32_t* __restrict__ tile_bin, int32_t tiles_x, int32_t tiles_y) {
   __shared__ int s_id[kBinCapMax];
   __shared__ float s_key[kBinCapMax];
-  __shared__ float4 s_bb[RTGS_TILE_BINS ? kBinCapMax : 1];      // bounds of the listed slabs, then in sorted order
-  __shared__ int s_sid[RTGS_TILE_BINS ? kBinCapMax : 1];         // sorted ids
+  __shared__ float4 s_bb[RTGS_TILE_BINS ? kBinCapMax : 1];      // bounds of the listed slabs (list order)
+  __shared__ int s_perm[RTGS_TILE_BINS ? kBinCapMax : 1];        // sorted position -> list position
   __shared__ int s_wc[2][4];
   constexpr int kGrpCap = RTGS_BIN_GROUPS;
   __shared__ int s_grp[kGroups ? kGrpCap : 1];
@@ -672,35 +663,25 @@ __global__ __launch_bounds__(256) void k_bin(int32_t nslabs, const float4* __res
     return;
   }
   __syncthreads();
-  // nearest first: rank by (key, slab id) -- the ids were listed in increasing order
-  constexpr int kPer = kBinCapMax / 256;
-  int rank[kPer];
-  float4 mybb[kPer];
-#pragma unroll
-  for (int q = 0; q < kPer; ++q) {
-    const int e = tid + q * 256;
-    rank[q] = -1;
-    if (e < cnt) {
-      const float my = s_key[e];
-      int r = 0;
-      for (int j = 0; j < cnt; ++j) {
-        const float kj = s_key[j];
-        r += (kj < my || (kj == my && j < e)) ? 1 : 0;
-      }
-      rank[q] = r;
-      bin_list[(size_t)st * stride + r] = s_id[e];
-      if constexpr (RTGS_TILE_BINS != 0) mybb[q] = s_bb[e];
+  // nearest first: rank by (key, slab id) -- the ids were listed in increasing order.  The rank goes
+  // straight to the bin (global) and, as the inverse permutation, to s_perm: nothing is carried in
+  // registers from this loop to the tile lists below (round 3 kept rank[4] + bounds[4] per thread,
+  // which the compiler put in 80 B of scratch per lane)
+  for (int e = tid; e < cnt; e += 256) {
+    const float my = s_key[e];
+    int r = 0;
+    for (int j = 0; j < cnt; ++j) {
+      const float kj = s_key[j];
+      r += (kj < my || (kj == my && j < e)) ? 1 : 0;
     }
+    bin_list[(size_t)st * stride + r] = s_id[e];
+    if constexpr (RTGS_TILE_BINS != 0) s_perm[r] = e;
   }
   if (tid == 0) bin_count[st] = cnt;
   if constexpr (RTGS_TILE_BINS != 0) {
     if (!tile_bin) return;
     // The macro-tiles' own lists: the sorted list filtered by each tile's bounds, order preserved (= what
     // the tile's filter of this bin would keep).  One wave per tile, 64 listed slabs per step.
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < kPer; ++q)
-      if (rank[q] >= 0) { s_bb[rank[q]] = mybb[q]; s_sid[rank[q]] = s_id[tid + q * 256]; }
     __syncthreads();
     const int per_edge = 1 << shift, ntl = per_edge * per_edge;
     // four tiles at a time per wave: one pass over the sorted list serves all four (the list entries are
@@ -727,7 +708,7 @@ __global__ __launch_bounds__(256) void k_bin(int32_t nslabs, const float4* __res
         const int e = base + lane;
         float4 b = make_float4(kInf, kInf, -kInf, -kInf);
         int id = 0;
-        if (e < cnt) { b = s_bb[e]; id = s_sid[e]; }
+        if (e < cnt) { const int at = s_perm[e]; b = s_bb[at]; id = s_id[at]; }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const bool keep = b.x <= tXhi[q] && b.z >= tXlo[q] && b.y <= tYhi[q] && b.w >= tYlo[q];
@@ -813,29 +794,14 @@ __device__ __forceinline__ void list_insert2(unsigned (&kt)[kK], unsigned (&kp)[
   for (int k = kB; k < kHi; ++k) lt[k - kB] = tn < kt[k];
 #pragma unroll
   for (int k = kHi - 1; k > kB; --k) {
-#if RTGS_MED3
-    // the list is sorted, so the new key of slot k is the median of (left neighbour, itself, new key)
+    // the list is sorted, so the new key of slot k is the median of (left neighbour, itself, new key):
+    // one v_med3_u32 instead of two selects (c3 0.1506 -> 0.1388 ms)
     kt[k] = max(min(kt[k - 1], kt[k]), min(max(kt[k - 1], kt[k]), tn));
-#else
-    kt[k] = lt[k - 1 - kB] ? kt[k - 1] : (lt[k - kB] ? tn : kt[k]);
-#endif
-#if RTGS_ABLATE_PAYLOAD   // (timing only -- one operation per payload slot instead of a compare and two selects)
-    kp[k] = min(kp[k] + 16u, pn);
-#else
     kp[k] = lt[k - 1 - kB] ? kp[k - 1] : (lt[k - kB] ? pn : kp[k]);
-#endif
   }
   if constexpr (kLo == 0) {
-#if RTGS_MED3
     kt[0] = min(kt[0], tn);
-#else
-    kt[0] = lt[0] ? tn : kt[0];
-#endif
-#if RTGS_ABLATE_PAYLOAD
-    kp[0] = min(kp[0] + 16u, pn);
-#else
     kp[0] = lt[0] ? pn : kp[0];
-#endif
   }
 }
 
@@ -861,6 +827,39 @@ __device__ __forceinline__ void sh_basis(float x, float y, float z, float (&Y)[R
   Y[14] = 0.25f * c3 * x * (x * x - 3.f * y * y);
 }
 
+// One ray against one projected record, operation for operation what k_trace's candidate loop does
+// with the record in SGPRs (same fmaf chains, same v_rcp / v_sqrt): t1 bits -- ~0u when the ray
+// misses or t1 <= start -- and the exponent delta/(4A).  Used by the tie fix-up at the end of
+// k_trace, where a lane holds a Gaussian and the pixel is wave-uniform; t1 MUST come out bit for bit
+// as in the candidate loop, because `t1 > start` is what keeps an entry from being found twice.
+__device__ __forceinline__ unsigned pair_eval(const float4* __restrict__ rec, const float4* __restrict__ tail, int g,
+                                              float X, float Y, float dlen, float start, float& wn) {
+  const float4* rp = rec + (size_t)g * (kRecFloats / 4);
+  const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
+  float x = X - q0.x;
+  float y = Y - q0.y;
+  float gx = q0.w;
+  const bool gen = __float_as_uint(q3.y) != 0u;
+  float A_gen = 0.f;
+  if (gen) {
+    const float4* tp = tail + (size_t)g * (kTailFloats / 4);
+    const float4 t0 = tp[0], t1v = tp[1];
+    if (t1v.w != 0.f) { const float t = x; x = y; y = t; }
+    gx = fmaf(-t1v.z, y, q0.w);
+    A_gen = fmaf(y, fmaf(t1v.y, y, t0.z), fmaf(x, fmaf(t1v.x, y, fmaf(t0.w, x, t0.y)), t0.x));
+  }
+  const float u = fmaf(q1.z, y, x);
+  float e = fmaf(x, gx, q0.z);
+  e = fmaf(y, fmaf(-q1.w, y, q1.x), e);
+  e = fmaf(-(q1.y * u), u, e);
+  const float bq = fmaf(q2.z, y, fmaf(q2.y, x, q2.x));
+  const bool hit = e > 0.f && bq < 0.f;
+  const float t1 = q2.w * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(e) - bq) * dlen;
+  const float A = gen ? A_gen : fmaf(bq, bq, -e) * q3.x;
+  wn = e * __builtin_amdgcn_rcpf(A);
+  return (hit && t1 > start && __float_as_uint(t1) < 0x7F800000u) ? __float_as_uint(t1) : ~0u;
+}
+
 // kK = list length: RTGS_MAX_DEPTH, or 1 for single-peel calls (the reference viewer's one
 // sample_step per frame), where the list degenerates to "the nearest hit so far".
 //
@@ -876,7 +875,9 @@ __device__ __forceinline__ void sh_basis(float x, float y, float z, float (&Y)[R
 // compositing loop will; if every ray of the tile is below the cut-off there -- or already holds
 // `depth` final entries -- a wave ballot skips the rest of the round.  Exact: a terminated ray
 // composites nothing behind those entries, so the image equals the compositing-only cut-off's.
-template <bool kHasSh, bool kBig, int kK, int kSplit, bool kCut = false>
+// kList (rtgs_trace_lists): the launch stores every ray's sorted distinct entries instead of compositing them
+// (an instantiation of its own: as a run-time branch it cost the main one five spilled VGPRs).
+template <bool kHasSh, bool kBig, int kK, int kSplit, bool kCut = false, bool kList = false>
 __global__ __launch_bounds__(kTraceBlock * kSplit,
                              kHasSh ? (kBig && kSplit == 1 ? RTGS_WAVES_PER_SIMD_SH : RTGS_WAVES_PER_SIMD)
                                     : (!kBig && kSplit == 1 && kK == RTGS_MAX_DEPTH ? RTGS_WAVES_PER_SIMD_MAIN
@@ -927,7 +928,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   static_assert(kRegionCap >= kSlab, "a region must hold one whole slab");
   __shared__ int s_rcnt[kRegions], s_rmore[kRegions];
   constexpr int kSuperStep = kSlabIters * kBlock;   // slab groups scanned per outer step
-  constexpr bool kTwo = kBig || RTGS_TWO_LEVEL;   // two-level slab scan
+  constexpr bool kTwo = kBig;   // two-level slab scan (small scenes: c3 0.260 vs 0.261 ms flat, one barrier more)
   __shared__ int s_super[kTwo ? kSuperStep : 1];
   __shared__ int s_wcnt2[2][kWaves];
 
@@ -983,6 +984,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   [[maybe_unused]] float* const s_wl = s_w + tid;
   constexpr bool kHorizon = RTGS_HORIZON != 0 && kK == RTGS_MAX_DEPTH;
   static_assert(!kCut || (kSplit == 1 && kK == RTGS_MAX_DEPTH), "traversal cut: one-wave full-list form only");
+  static_assert(!kList || (kSplit == 1 && kK == RTGS_MAX_DEPTH && !kCut), "peel lists: one-wave full-list form only");
   constexpr int kChunksMax = kListCap / kWave;
   __shared__ float s_smin[kCut ? kWaves * kChunksMax : 1];   // per wave: suffix minima of the chunks' distance bounds
   [[maybe_unused]] float T_in = 1.f;                            // attenuation this call starts from
@@ -990,7 +992,8 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
     if ((a.flags & RTGS_TRACE_RESUME) && in_img) T_in = a.att[(size_t)pi * a.height + pj];
   }
   constexpr bool kLookahead = RTGS_LOOKAHEAD == 2 || (RTGS_LOOKAHEAD == 1 && kBig);
-  constexpr int kTier = (kLdsW && RTGS_TIER > 0 && RTGS_TIER < kK) ? RTGS_TIER : kK;
+  static_assert(RTGS_TIER > 0 && RTGS_TIER < RTGS_MAX_DEPTH, "the tier boundary lies inside the list");
+  constexpr int kTier = kLdsW ? RTGS_TIER : kK;
   [[maybe_unused]] bool tier_short = kTier < kK;   // wave-uniform: slot kTier-1 still empty in every lane
 
   // set bits of a wave mask below this lane: v_mbcnt_lo/hi straight from the SGPR pair
@@ -1390,12 +1393,8 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
             hit = hit && bq < 0.f;   // the cone half in front of the camera
             // smaller root of A t^2 + 2 b t + C (gaussian.py:224) in its cancellation-free form
             // t1 = C / (sqrt(delta/4) - b): C > 0 and b < 0, so nothing is subtracted.
-            // v_sqrt_f32 / v_rcp_f32 are 1 ulp: far inside the 1e-4 pixel tolerance.
-#if RTGS_FAST_DIV
+            // v_sqrt_f32 / v_rcp_f32 are 1 ulp: far inside the 1e-4 pixel tolerance (IEEE division / sqrt: +8 %).
             const float t1 = q2.w * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(e) - bq) * dlen;
-#else
-            const float t1 = (q2.w / (sqrtf(e) - bq)) * dlen;
-#endif
             // scene.py:433: start < t1 < end, end = +inf for a camera ray (an overflowed t1 = +inf has the
             // bits of an empty slot and fails the insertion test below by itself; NaN fails `>`)
             const bool cand = hit && t1 > start;
@@ -1414,11 +1413,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
 #endif
               // A = d^T Sigma^-1 d from delta/4 = b^2 - A C (compact records), or its own polynomial
               const float A = gen ? A_gen : fmaf(bq, bq, -e) * q3.x;
-#if RTGS_FAST_DIV
               const float wn = e * __builtin_amdgcn_rcpf(A);
-#else
-              const float wn = e / A;
-#endif
 #if RTGS_ABLATE == 1
               asm volatile("" ::"v"(kn), "v"(wn));
 #else
@@ -1434,7 +1429,6 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
                 const unsigned slot = (tier_short ? kidx[kTier - 1] : kidx[kK - 1]) & kSlotMask;
                 const unsigned pn = (entry << kSlotBits) | slot;
                 if (ins) s_wl[(slot & 15u) * kBlock] = wn;
-#if RTGS_SKIP_LOWER
                 // Slot k of a lane changes iff kn < key[k] (kn = ~0 where the lane does not insert), so the
                 // lower half is untouched in the whole wave unless some lane has kn below key[kTier-1]:
                 // one compare + ballot skips it -- candidates arrive nearest first, so the later ones
@@ -1449,12 +1443,6 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
                   if (!tier_short) list_insert2<kTier, kK>(key, kidx, kn, pn);
                 }
                 if (low) list_insert2<0, kTier>(key, kidx, kn, pn);
-#else
-                if constexpr (kTier < kK) {
-                  if (!tier_short) list_insert2<kTier, kK>(key, kidx, kn, pn);
-                }
-                list_insert2<0, kTier>(key, kidx, kn, pn);
-#endif
                 if constexpr (kTier < kK) {
                   if (tier_short) tier_short = !wave_any(key[kTier - 1] < kEmpty);
                 }
@@ -1559,6 +1547,114 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   KArgs* ea = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   asm volatile("" : "+s"(ea));
   const size_t pix = (size_t)pi_e * ea->height + pj_e;
+
+  // The next entry of ONE ray beyond distance sf, found by the whole wave: every lane takes one Gaussian of a
+  // slab that covers the pixel and evaluates it for THAT pixel with the candidate loop's own arithmetic
+  // (pair_eval); of exactly tied entries the lower Gaussian index wins.  Wave-uniform results; false = the
+  // ray misses.  Cold code: only the tie fix-up (below) calls it.
+  [[maybe_unused]] auto find_next = [&](float Xf, float Yf, float dlf, float sf, unsigned& t_out, unsigned& g_out, float& w_out) -> bool {
+    const int n_g = ea->n, nsl = (n_g + kSlab - 1) / kSlab;
+    // the tile's own depth-sorted slab list when the frame has one, else every slab
+    // (tile and bin recomputed from the kernarg segment: nothing of this path is kept alive through the candidate loop)
+    const int32_t* tbl = nullptr;
+    int nlist = nsl;
+    if constexpr (RTGS_TILE_BINS != 0) {
+      const int tile_f = ea->tile_first + ltile * ea->tile_step;
+      const int bin_f = ((tile_f / ea->tiles_x) >> ea->bin_shift) * ea->bin_sx + ((tile_f % ea->tiles_x) >> ea->bin_shift);
+      if (ea->tile_bin && ea->bin_count && __builtin_amdgcn_readfirstlane(ea->bin_count[bin_f]) >= 0) {
+        const int32_t* const tb = ea->tile_bin + (size_t)tile_f * kTileBinCap;
+        const int c = __builtin_amdgcn_readfirstlane(tb[0]);
+        if (c >= 0) { tbl = tb + 1; nlist = c; }
+      }
+    }
+    unsigned bt = ~0u, bg = ~0u;   // this lane's best (t1 bits, Gaussian) beyond sf
+    float bw = 0.f;
+    for (int base = 0; base < nlist; base += kWave) {
+      const int li = base + lane;
+      int sl = -1;
+      if (li < nlist) sl = tbl ? tbl[li] : li;
+      bool touch = false;
+      if (sl >= 0) {
+        const float4 sb = slab_bbox[sl];
+        touch = sb.x <= Xf && sb.z >= Xf && sb.y <= Yf && sb.w >= Yf;
+      }
+      unsigned long long sm = __builtin_amdgcn_ballot_w64(touch);
+      while (sm) {
+        const int sb_ = __builtin_ctzll(sm);
+        sm &= sm - 1ull;
+        const int g = __builtin_amdgcn_readlane(sl, sb_) * kSlab + lane;
+        if (g < n_g) {
+          const float4 gb = bbox[g];
+          if (gb.x <= Xf && gb.z >= Xf && gb.y <= Yf && gb.w >= Yf) {
+            float w1;
+            const unsigned tb1 = pair_eval(rec, tail, g, Xf, Yf, dlf, sf, w1);
+            if (tb1 < bt || (tb1 == bt && (unsigned)g < bg)) { bt = tb1; bg = (unsigned)g; bw = w1; }
+          }
+        }
+      }
+    }
+    const unsigned tmin1 = wave_umin(bt);
+    if (tmin1 >= kEmpty) return false;
+    const unsigned gmin = wave_umin(bt == tmin1 ? bg : ~0u);
+    const int wl = __builtin_ctzll(__builtin_amdgcn_ballot_w64(bt == tmin1 && bg == gmin));
+    t_out = tmin1;
+    g_out = gmin;
+    w_out = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(bw), wl));
+    return true;
+  };
+  [[maybe_unused]] auto lane_f = [](float v, int l) { return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), l)); };
+
+  if constexpr (kList) {
+    {
+      // ---- list form (rtgs_trace_lists): no compositing; the sorted DISTINCT entries of every ray go to the
+      // peel lists, [tile][slot][thread], for rtgs_peel to composite one per call (the reference viewer's
+      // sample() pattern, __main__.py:253-256: 16 calls, ONE traversal).  A tied twin is dropped here, and a
+      // full list that came up short that way is topped up by the wave (the tie fix-up, list form).
+      const int tile_l = ea->tile_first + ltile * ea->tile_step;
+      const size_t lbase = (size_t)tile_l * (kK * kTraceBlock) + (size_t)(sub * kWave + lane_e);
+      int cnt = 0;
+      unsigned prev = 0u;
+#pragma unroll
+      for (int k = 0; k < kK; ++k) {
+        const unsigned tb = key[k];
+        const bool valid = in_img && tb < kEmpty && tb != prev;
+        prev = tb;
+        if (valid) {
+          const size_t at = lbase + (size_t)cnt * kTraceBlock;
+          ea->list_idx[at] = (int32_t)(kidx[k] >> kSlotBits);
+          ea->list_w[at] = s_wl[(kidx[k] & 15u) * kBlock];
+          ea->list_t[at] = __uint_as_float(tb);
+          ++cnt;
+        }
+      }
+      unsigned long long fix_l = __builtin_amdgcn_ballot_w64(in_img && cnt < kK && key[kK - 1] < kEmpty);
+      while (__builtin_expect(fix_l != 0ull, 0)) {
+        const int fl = __builtin_ctzll(fix_l);
+        fix_l &= fix_l - 1ull;
+        const float Xf = lane_f(X, fl), Yf = lane_f(Y, fl), dlf = lane_f(dlen, fl);
+        float sf = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)key[kK - 1], fl));
+        int left = kK - __builtin_amdgcn_readlane(cnt, fl);
+        unsigned tn, gn;
+        float wn;
+        while (left > 0 && find_next(Xf, Yf, dlf, sf, tn, gn, wn)) {
+          if (lane == fl) {
+            const size_t at = lbase + (size_t)cnt * kTraceBlock;
+            ea->list_idx[at] = (int32_t)gn;
+            ea->list_w[at] = wn;
+            ea->list_t[at] = __uint_as_float(tn);
+            ++cnt;
+          }
+          sf = __uint_as_float(tn);
+          --left;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < kK; ++k)
+        if (k >= cnt) ea->list_idx[lbase + (size_t)k * kTraceBlock] = -1;
+      return;
+    }
+  }
+
   float T = 1.f;
 #if !RTGS_STAMPS
   if ((ea->flags & RTGS_TRACE_RESUME) && in_img) T = ea->att[pix];
@@ -1592,9 +1688,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
     // slots beyond the first `depth` only matter to lanes that dropped an exact t1 tie on the way
     // (the reference's peel loop peels on until `depth` DISTINCT entry distances are composited)
     if (k0 >= ea->depth && !wave_any(nhit < ea->depth && key[k0] < kEmpty)) break;
-#if RTGS_COMPOSITE_EXIT
     if (k0 > 0 && !wave_any(key[k0] < kEmpty)) break;   // every list of the wave ends before this group
-#endif
     float4 cog[kGroup];
     [[maybe_unused]] float wl[kGroup];
 #pragma unroll
@@ -1619,7 +1713,9 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
         // transmittance cut-off (extension, off by default): a ray below it stops compositing
         // -- as if it had missed, ray.start = +inf -- and a wave ballot ends the loop
         const bool live = valid && !(ea->t_cutoff > 0.f && T < ea->t_cutoff);
-        if (ea->t_cutoff > 0.f && !wave_any(live)) { done = true; continue; }
+        // (the ballot asks whether any ray can still composite something at this slot OR LATER: a slot that
+        // merely repeats the previous entry distance must not end the loop for the entries behind it)
+        if (ea->t_cutoff > 0.f && !wave_any(tbits < kEmpty && nhit < ea->depth && !(T < ea->t_cutoff))) { done = true; continue; }
         prev_tbits = tbits;
         float4 co = cog[j];
         if (kHasSh) {
@@ -1631,50 +1727,17 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
             // 0.317, c5 1.30 -> 1.99: one event's 45 coefficients at a time leaves the scalar-load
             // latency exposed, the log's LDS costs c5 a workgroup per CU, and 23 x 68 v_pk_fma_f32
             // per wave is 1.6 x the arithmetic of 14 x 68.  Coefficients read per lane from LDS
-            // instead (timing-only build RTGS_SH_ABLATE=3, nothing staged): c3 + SH 0.290 -> 0.200,
+            // instead (timing-only build of round 2, nothing staged): c3 + SH 0.290 -> 0.200,
             // c5 1.306 -> 1.122 -- the bound of staging a wave's distinct Gaussians in LDS; but the
             // 192 B per staged Gaussian cost a workgroup per CU beyond ~20 per wave, and with one
             // workgroup less the same builds run at 0.281 / 1.385: nothing left.)
             const float* sp = sh + (size_t)gi * (RTGS_SH_COEFFS * 3);
-#if RTGS_SH_ABLATE == 3   // timing only: the coefficients from LDS (whatever s_w holds) instead of memory
-            if constexpr (kLdsW) {
-              const float4* lp = reinterpret_cast<const float4*>(s_w) + (gi & 63u) * 12u;   // 48-float records
-              float cf[48];
-#pragma unroll
-              for (int j = 0; j < 12; ++j) {
-                const float4 v = lp[j];
-                cf[4 * j] = v.x; cf[4 * j + 1] = v.y; cf[4 * j + 2] = v.z; cf[4 * j + 3] = v.w;
-              }
-#pragma unroll
-              for (int q = 0; q < RTGS_SH_COEFFS; ++q) {
-                co.x += Ysh[q] * cf[3 * q + 0];
-                co.y += Ysh[q] * cf[3 * q + 1];
-                co.z += Ysh[q] * cf[3 * q + 2];
-              }
-            }
-#elif RTGS_SH_ABLATE == 1   // timing only: the loads without the arithmetic
-#pragma unroll
-            for (int q = 0; q < RTGS_SH_COEFFS; ++q) {
-              float v0 = sp[3 * q + 0], v1 = sp[3 * q + 1], v2 = sp[3 * q + 2];
-              asm volatile("" :: "v"(v0), "v"(v1), "v"(v2));
-            }
-#elif RTGS_SH_ABLATE == 2   // timing only: the arithmetic without the loads
-            float f0 = co.x, f1 = co.y, f2 = co.z;
-#pragma unroll
-            for (int q = 0; q < RTGS_SH_COEFFS; ++q) {
-              asm volatile("" : "+v"(f0), "+v"(f1), "+v"(f2));
-              co.x += Ysh[q] * f0;
-              co.y += Ysh[q] * f1;
-              co.z += Ysh[q] * f2;
-            }
-#else
 #pragma unroll
             for (int q = 0; q < RTGS_SH_COEFFS; ++q) {
               co.x += Ysh[q] * sp[3 * q + 0];
               co.y += Ysh[q] * sp[3 * q + 1];
               co.z += Ysh[q] * sp[3 * q + 2];
             }
-#endif
           }
         }
         float wk;
@@ -1686,6 +1749,55 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
           T *= 1.0f - alpha;
           last_t = __uint_as_float(tbits);
           ++nhit;
+        }
+      }
+    }
+  }
+
+  // ---- tie fix-up (round 4).  The reference composites `depth` DISTINCT entry distances
+  // (scene.py:433 `intersections.x > ray.start` after ray_tracer.py:101); this launch kept the kK
+  // nearest ENTRIES, and an exactly tied twin took one of the slots.  A lane whose list is full but
+  // which has composited fewer than `depth` distinct entries (a few dozen pixels of a 1080p frame)
+  // peels on here, with the whole wave's help: every lane takes one Gaussian of a slab that covers the
+  // pixel, evaluates it for THAT pixel with the candidate loop's own arithmetic (pair_eval), and the
+  // nearest entry beyond the lane's last one is composited -- the reference's next peel, literally --
+  // until `depth` are done or the ray misses.  Cold code: one ballot per wave when there is no tie.
+  if constexpr (kK > 1) {
+    unsigned long long fix_m = __builtin_amdgcn_ballot_w64(in_img && nhit < ea->depth && key[kK - 1] < kEmpty &&
+                                                           !(ea->t_cutoff > 0.f && T < ea->t_cutoff));
+    if (__builtin_expect(fix_m != 0ull, 0)) {
+      while (fix_m) {
+        const int fl = __builtin_ctzll(fix_m);
+        fix_m &= fix_m - 1ull;
+        const float Xf = lane_f(X, fl), Yf = lane_f(Y, fl), dlf = lane_f(dlen, fl);
+        float sf = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)key[kK - 1], fl));
+        int left = ea->depth - __builtin_amdgcn_readlane(nhit, fl);
+        unsigned tmin1, gmin;
+        float wk;
+        while (left > 0 && find_next(Xf, Yf, dlf, sf, tmin1, gmin, wk)) {
+          bool stop = false;
+          if (lane == fl) {
+            float4 co = colop[gmin];
+            if (kHasSh) {
+              const float* sp = sh + (size_t)gmin * (RTGS_SH_COEFFS * 3);
+#pragma unroll
+              for (int q = 0; q < RTGS_SH_COEFFS; ++q) {
+                co.x += Ysh[q] * sp[3 * q + 0];
+                co.y += Ysh[q] * sp[3 * q + 1];
+                co.z += Ysh[q] * sp[3 * q + 2];
+              }
+            }
+            const float alpha = co.w * exp_m3(wk);
+            const float wa = T * alpha;
+            L0 += wa * co.x; L1 += wa * co.y; L2 += wa * co.z;
+            T *= 1.0f - alpha;
+            last_t = __uint_as_float(tmin1);
+            ++nhit;
+            stop = ea->t_cutoff > 0.f && T < ea->t_cutoff;   // below the cut-off: stopped for good
+          }
+          if (__builtin_amdgcn_ballot_w64(stop) != 0ull) break;
+          sf = __uint_as_float(tmin1);
+          --left;
         }
       }
     }
@@ -1731,19 +1843,97 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
 #if !RTGS_STAMPS
     if (ea->att) ea->att[pix] = T;
 #endif
-    // ray_tracer.py:99-104: start = t1 + EPS after a hit, +inf after a miss.  A list that is FULL
-    // although fewer than `depth` distinct entries were composited lost slots to exact t1 ties: the
-    // ray has not missed -- the next peel (a resumed launch: depth > RTGS_MAX_DEPTH is a chain of
-    // them) goes on behind the list's last entry.  A ray below the cut-off has stopped for good.
-    if (ea->start) {
-      float s_out = (nhit == ea->depth) ? last_t + 1e-8f : kInf;
-      if constexpr (kK > 1) {
-        if (nhit < ea->depth && key[kK - 1] < kEmpty && !(ea->t_cutoff > 0.f && T < ea->t_cutoff))
-          s_out = __uint_as_float(key[kK - 1]) + 1e-8f;
-      }
-      ea->start[pix * ea->start_stride] = s_out;
+    // ray_tracer.py:99-104: start = t1 + EPS after a hit, +inf after a miss (fewer than `depth`
+    // distinct entries: the tie fix-up above has peeled on until the ray really missed) or below the cut-off
+    if (ea->start) ea->start[pix * ea->start_stride] = (nhit == ea->depth) ? last_t + 1e-8f : kInf;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// peel lists: the reference viewer's one-peel-per-call pattern from ONE traversal
+// ------------------------------------------------------------------------------------
+struct PeelArgs {
+  int32_t width, height, tiles_x;
+  int32_t k;            // which entry of every ray's list this call composites (0 = the nearest)
+  uint32_t fresh;       // the sample starts here: attenuation 1 instead of attenuation_buf (clear_attenuation)
+  float inv_fx, inv_fy;
+  float rc[9];
+  const FrameCam* pose;
+  const int32_t* list_idx;
+  const float* list_w;
+  float* sample;
+  float* att;
+};
+
+// RayTracer.sample_step (ray_tracer.py:79-104) for camera rays whose sorted entries k_trace has already
+// listed: sample += attenuation * alpha * colour, attenuation *= 1 - alpha for entry k of every ray -- what
+// the K = 1 resumed launch computes after re-traversing the tile.  Same thread <-> pixel map as k_trace, so
+// a list slot is one coalesced 1 KB read per workgroup.
+template <bool kHasSh>
+__global__ __launch_bounds__(kTraceBlock) void k_peel(const PeelArgs a, const float4* __restrict__ colop,
+                                                       const float* __restrict__ sh) {
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), sub = tid >> 6;
+  const int tile = blockIdx.x;
+  const int pi = (tile % a.tiles_x) * kTile + (sub % kWavesX) * kWaveTile + (lane >> 3);
+  const int pj = (tile / a.tiles_x) * kTile + (sub / kWavesX) * kWaveTile + (lane & 7);
+  if (pi >= a.width || pj >= a.height) return;
+  const size_t at = ((size_t)tile * RTGS_MAX_DEPTH + a.k) * kTraceBlock + tid;
+  const int gi = a.list_idx[at];
+  const size_t pix = (size_t)pi * a.height + pj;
+  if (gi < 0) {                      // a miss (ray_tracer.py:103-104): nothing to add
+    if (a.fresh) a.att[pix] = 1.0f;
+    return;
+  }
+  const float wk = a.list_w[at];
+  float T = a.fresh ? 1.0f : a.att[pix];
+  float4 co = colop[gi];
+  if (kHasSh) {
+    const float hw = 0.5f * (float)a.width, hh = 0.5f * (float)a.height;
+    const float dcx = (((float)pi + 0.5f) - hw) * a.inv_fx, dcy = (((float)pj + 0.5f) - hh) * a.inv_fy;
+    const float il = 1.0f / sqrtf(dcx * dcx + dcy * dcy + 1.0f);
+    const float cx = dcx * il, cy = dcy * il, cz = -il;
+    float rcf[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) rcf[k] = a.pose ? (float)a.pose->rc[k] : a.rc[k];
+    const float wx = rcf[0] * cx + rcf[1] * cy + rcf[2] * cz;
+    const float wy = rcf[3] * cx + rcf[4] * cy + rcf[5] * cz;
+    const float wz = rcf[6] * cx + rcf[7] * cy + rcf[8] * cz;
+    const float in = 1.0f / sqrtf(wx * wx + wy * wy + wz * wz);  // gaussian.py:200
+    float Ysh[RTGS_SH_COEFFS];
+    sh_basis(wx * in, wy * in, wz * in, Ysh);
+    const float* sp = sh + (size_t)gi * (RTGS_SH_COEFFS * 3);
+#pragma unroll
+    for (int q = 0; q < RTGS_SH_COEFFS; ++q) {
+      co.x += Ysh[q] * sp[3 * q + 0];
+      co.y += Ysh[q] * sp[3 * q + 1];
+      co.z += Ysh[q] * sp[3 * q + 2];
     }
   }
+  const float alpha = co.w * exp_m3(wk);
+  const float wa = T * alpha;
+  float* o = a.sample + pix * 3;
+  const Rgb old = *reinterpret_cast<const Rgb*>(o);
+  *reinterpret_cast<Rgb*>(o) = Rgb{old.r + wa * co.x, old.g + wa * co.y, old.b + wa * co.z};
+  a.att[pix] = T * (1.0f - alpha);
+}
+
+// cam_ray_field.start after `done` peels of the listed sample (ray_tracer.py:99-104): t1 of the last peel
+// + 1e-8, +inf once a peel has missed, 0 before the first
+__global__ __launch_bounds__(kTraceBlock) void k_peel_start(int32_t width, int32_t height, int32_t tiles_x, int32_t done,
+                                                             const int32_t* __restrict__ list_idx,
+                                                             const float* __restrict__ list_t,
+                                                             float* __restrict__ start, int32_t stride) {
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), sub = tid >> 6;
+  const int tile = blockIdx.x;
+  const int pi = (tile % tiles_x) * kTile + (sub % kWavesX) * kWaveTile + (lane >> 3);
+  const int pj = (tile / tiles_x) * kTile + (sub / kWavesX) * kWaveTile + (lane & 7);
+  if (pi >= width || pj >= height) return;
+  float s_out = 0.f;
+  if (done > 0) {
+    const size_t at = ((size_t)tile * RTGS_MAX_DEPTH + (done - 1)) * kTraceBlock + tid;
+    s_out = list_idx[at] >= 0 ? list_t[at] + 1e-8f : kInf;
+  }
+  start[((size_t)pi * height + pj) * stride] = s_out;
 }
 
 // rank_stride: tiles between consecutive ranks' blocks (tiles_per_rank for one frame per gather,
@@ -1920,21 +2110,23 @@ static int project_impl(const RtgsScene* scene, const RtgsCamera* cam, void* wor
   float* tmin = tail + nn * kTailFloats;
   float4* slab_bbox = reinterpret_cast<float4*>(tmin + nn);
   const FrameCam fc = make_frame_cam(*cam);
-  const int block = 256;
   const int nslabs = (int)(nn / kSlab);
   const bool bins = use_bins(nslabs) && want_bins;
   int32_t* const bin_count = reinterpret_cast<int32_t*>(slab_key_of(slab_bbox, nn) + ((nslabs + 3) & ~3));
-  hipLaunchKernelGGL(k_project, dim3((scene->n + block - 1) / block), dim3(block), 0,
-                     static_cast<hipStream_t>(stream), scene->n, scene->position, scene->rotation,
-                     scene->scale, fc, static_cast<const FrameCam*>(cam->device_pose), bbox, slab_bbox,
-                     slab_key_of(slab_bbox, nn), rec, tail, tmin,
-                     (use_bins(nslabs) && !bins) ? bin_count : nullptr);
-  const bool groups = nslabs > kBigSceneSlabs || RTGS_TWO_LEVEL;
-  if (groups) {
-    const int nsuper = (nslabs + kSuper - 1) / kSuper;
-    hipLaunchKernelGGL(k_super_bbox, dim3((nsuper + block - 1) / block), dim3(block), 0,
-                       static_cast<hipStream_t>(stream), nslabs, slab_bbox, slab_bbox + nslabs);
-  }
+  const bool groups = nslabs > kBigSceneSlabs;   // the scenes k_trace / k_bin scan in two levels (Tune<true>)
+  static_assert(kSuper * kSlab == 1024, "k_project<1024>: one block = one group of slabs");
+  if (groups)
+    hipLaunchKernelGGL(k_project<kSuper * kSlab>, dim3((scene->n + kSuper * kSlab - 1) / (kSuper * kSlab)), dim3(kSuper * kSlab), 0,
+                       static_cast<hipStream_t>(stream), scene->n, scene->position, scene->rotation,
+                       scene->scale, fc, static_cast<const FrameCam*>(cam->device_pose), bbox, slab_bbox,
+                       slab_bbox + nslabs, slab_key_of(slab_bbox, nn), rec, tail, tmin,
+                       (use_bins(nslabs) && !bins) ? bin_count : nullptr);
+  else
+    hipLaunchKernelGGL(k_project<256>, dim3((scene->n + 255) / 256), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), scene->n, scene->position, scene->rotation,
+                       scene->scale, fc, static_cast<const FrameCam*>(cam->device_pose), bbox, slab_bbox,
+                       nullptr, slab_key_of(slab_bbox, nn), rec, tail, tmin,
+                       (use_bins(nslabs) && !bins) ? bin_count : nullptr);
   if (bins) {
     const BinGeom g = bin_geom(cam->width, cam->height);
     float* keys = slab_key_of(slab_bbox, nn);
@@ -1976,11 +2168,11 @@ extern "C" int rtgs_project_shard(const RtgsScene* scene, const RtgsCamera* cam,
 static int trace_impl(const RtgsScene* scene, const RtgsCamera* cam, const RtgsTraceParams* params,
                       float* sample_buf, float* attenuation_buf, float* ray_start,
                       int32_t ray_start_stride, void* workspace, size_t workspace_bytes,
-                      int32_t projected, int32_t tile_limit, rtgs_stream_t stream) {
-  if (!params || !sample_buf) return RTGS_EINVAL;
+                      int32_t projected, int32_t tile_limit, rtgs_stream_t stream, void* lists = nullptr) {
+  if (!params || (!sample_buf && !lists)) return RTGS_EINVAL;
   if (int rc = validate(scene, cam, workspace, workspace_bytes)) return rc;
   if (params->depth < 1) return RTGS_EDEPTH;
-  if (params->depth > RTGS_MAX_DEPTH) {
+  if (params->depth > RTGS_MAX_DEPTH && !lists) {
     // The reference's depth is unbounded (__main__.py:66-71: one peel per sample() call, as many
     // as asked for).  A launch keeps RTGS_MAX_DEPTH entries per ray; more peels are a CHAIN of
     // launches through the per-pixel state -- each resumes behind the last entry of the one before
@@ -1993,7 +2185,7 @@ static int trace_impl(const RtgsScene* scene, const RtgsCamera* cam, const RtgsT
       p.depth = left > RTGS_MAX_DEPTH ? RTGS_MAX_DEPTH : left;
       if (link > 0) p.flags |= RTGS_TRACE_RESUME | RTGS_TRACE_ACCUMULATE;
       if (int rc = trace_impl(scene, cam, &p, sample_buf, attenuation_buf, ray_start, ray_start_stride,
-                              workspace, workspace_bytes, link > 0 ? 1 : projected, tile_limit, stream))
+                              workspace, workspace_bytes, link > 0 ? 1 : projected, tile_limit, stream, nullptr))
         return rc;
       left -= p.depth;
     }
@@ -2051,6 +2243,13 @@ static int trace_impl(const RtgsScene* scene, const RtgsCamera* cam, const RtgsT
   a.start = ray_start;
   a.start_stride = ray_start ? ray_start_stride : 1;
   a.tile_order = params->tile_order;
+  a.list_idx = nullptr; a.list_w = nullptr; a.list_t = nullptr;
+  if (lists) {
+    const size_t slots = (size_t)rtgs_num_tiles(cam->width, cam->height) * RTGS_MAX_DEPTH * kTraceBlock;
+    a.list_idx = static_cast<int32_t*>(lists);
+    a.list_w = reinterpret_cast<float*>(a.list_idx + slots);
+    a.list_t = a.list_w + slots;
+  }
   a.idx_bits = 1;
   while (a.idx_bits < 31 && (1u << a.idx_bits) < (uint32_t)scene->n) ++a.idx_bits;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -2063,17 +2262,20 @@ static int trace_impl(const RtgsScene* scene, const RtgsCamera* cam, const RtgsT
   if (params->flags & RTGS_TRACE_SPLIT_ON) split = true;
   if (params->flags & RTGS_TRACE_SPLIT_OFF) split = false;
   if (params->depth == 1) split = false;
+  const bool k1 = params->depth == 1 && !lists;   // (the list form always keeps RTGS_MAX_DEPTH entries)
   // the cut-off's traversal cut has its own instantiation of the one-wave full-list form
-  const bool cut = RTGS_CUT_TRAVERSAL != 0 && params->t_cutoff > 0.f && params->depth > 1;
+  const bool cut = RTGS_CUT_TRAVERSAL != 0 && params->t_cutoff > 0.f && params->depth > 1 && !lists;
   if (a.idx_bits > 17) split = false;   // two-wave entries: rank | index | 5 slot bits in 32; 10 rank bits need n <= 131072
 #define RTGS_LAUNCH(HAS_SH, BIG, K, SPLIT)                                                         \
   hipLaunchKernelGGL((k_trace<HAS_SH, BIG, K, SPLIT>), dim3(local), dim3(kTraceBlock * SPLIT), 0, s, a, \
                      bbox, slab_bbox, super_bbox, rec, tail, tmin, colop, sh)
 #define RTGS_LAUNCH_K(HAS_SH, BIG)                                                  \
   do {                                                                              \
-    if (cut) hipLaunchKernelGGL((k_trace<HAS_SH, BIG, RTGS_MAX_DEPTH, 1, true>), dim3(local), dim3(kTraceBlock), 0, s, a, \
+    if (lists) hipLaunchKernelGGL((k_trace<HAS_SH, BIG, RTGS_MAX_DEPTH, 1, false, true>), dim3(local), dim3(kTraceBlock), 0, s, a, \
+                                  bbox, slab_bbox, super_bbox, rec, tail, tmin, colop, sh);                              \
+    else if (cut) hipLaunchKernelGGL((k_trace<HAS_SH, BIG, RTGS_MAX_DEPTH, 1, true>), dim3(local), dim3(kTraceBlock), 0, s, a, \
                                 bbox, slab_bbox, super_bbox, rec, tail, tmin, colop, sh);                                \
-    else if (params->depth == 1) RTGS_LAUNCH(HAS_SH, BIG, 1, 1);                    \
+    else if (k1) RTGS_LAUNCH(HAS_SH, BIG, 1, 1);                                    \
     else if (split) RTGS_LAUNCH(HAS_SH, BIG, RTGS_MAX_DEPTH, 2);                    \
     else RTGS_LAUNCH(HAS_SH, BIG, RTGS_MAX_DEPTH, 1);                               \
   } while (0)
@@ -2092,6 +2294,69 @@ int rtgs_trace(const RtgsScene* scene, const RtgsCamera* cam, const RtgsTracePar
                int32_t projected, rtgs_stream_t stream) {
   return trace_impl(scene, cam, params, sample_buf, attenuation_buf, ray_start, ray_start_stride,
                     workspace, workspace_bytes, projected, INT32_MAX, stream);
+}
+
+// ---- peel lists (ABI v6): the reference viewer calls sample() `depth` times per sample (__main__.py:253-256,
+// ray_tracer.py:39-54), one peel each; rtgs_trace_lists traverses ONCE and stores every ray's sorted distinct
+// entries, rtgs_peel composites entry k of every ray, rtgs_peel_start writes the ray.start the peels so far imply.
+
+size_t rtgs_peel_list_bytes(int32_t width, int32_t height) {
+  return (size_t)rtgs_num_tiles(width, height) * RTGS_MAX_DEPTH * kTraceBlock * (sizeof(int32_t) + 2 * sizeof(float));
+}
+
+int rtgs_trace_lists(const RtgsScene* scene, const RtgsCamera* cam, const int32_t* tile_order, void* lists,
+                     size_t lists_bytes, void* workspace, size_t workspace_bytes, int32_t projected,
+                     rtgs_stream_t stream) {
+  if (!cam || !lists || (reinterpret_cast<uintptr_t>(lists) & 15u)) return RTGS_EINVAL;
+  if (lists_bytes < rtgs_peel_list_bytes(cam->width, cam->height)) return RTGS_EWORKSPACE;
+  RtgsTraceParams p;
+  p.depth = RTGS_MAX_DEPTH;
+  p.t_cutoff = 0.f;
+  p.tile_first = 0;
+  p.tile_step = 1;
+  p.flags = RTGS_TRACE_SPLIT_OFF;
+  p.tile_order = tile_order;
+  return trace_impl(scene, cam, &p, nullptr, nullptr, nullptr, 1, workspace, workspace_bytes, projected, INT32_MAX,
+                    stream, lists);
+}
+
+int rtgs_peel(const RtgsScene* scene, const RtgsCamera* cam, const void* lists, size_t lists_bytes, int32_t k,
+              uint32_t flags, float* sample_buf, float* attenuation_buf, rtgs_stream_t stream) {
+  if (!scene || !cam || !lists || !sample_buf || !attenuation_buf || !scene->color_opacity) return RTGS_EINVAL;
+  if (cam->width <= 0 || cam->height <= 0 || !(cam->fx > 0.f) || !(cam->fy > 0.f)) return RTGS_EINVAL;
+  if (k < 0 || k >= RTGS_MAX_DEPTH) return RTGS_EDEPTH;
+  if (lists_bytes < rtgs_peel_list_bytes(cam->width, cam->height)) return RTGS_EWORKSPACE;
+  const FrameCam fc = make_frame_cam(*cam);
+  const int32_t tiles = rtgs_num_tiles(cam->width, cam->height);
+  const size_t slots = (size_t)tiles * RTGS_MAX_DEPTH * kTraceBlock;
+  PeelArgs a;
+  a.width = cam->width; a.height = cam->height; a.tiles_x = (cam->width + kTile - 1) / kTile;
+  a.k = k; a.fresh = (flags & RTGS_PEEL_FRESH) ? 1u : 0u;
+  a.inv_fx = (float)fc.inv_fx; a.inv_fy = (float)fc.inv_fy;
+  for (int q = 0; q < 9; ++q) a.rc[q] = (float)fc.rc[q];
+  a.pose = static_cast<const FrameCam*>(cam->device_pose);
+  a.list_idx = static_cast<const int32_t*>(lists);
+  a.list_w = reinterpret_cast<const float*>(a.list_idx + slots);
+  a.sample = sample_buf; a.att = attenuation_buf;
+  const float4* colop = reinterpret_cast<const float4*>(scene->color_opacity);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (scene->sh) hipLaunchKernelGGL(k_peel<true>, dim3(tiles), dim3(kTraceBlock), 0, s, a, colop, scene->sh);
+  else hipLaunchKernelGGL(k_peel<false>, dim3(tiles), dim3(kTraceBlock), 0, s, a, colop, scene->sh);
+  return check_launch();
+}
+
+int rtgs_peel_start(const RtgsCamera* cam, const void* lists, size_t lists_bytes, int32_t peels_done,
+                    float* ray_start, int32_t ray_start_stride, rtgs_stream_t stream) {
+  if (!cam || !lists || !ray_start || ray_start_stride <= 0 || cam->width <= 0 || cam->height <= 0) return RTGS_EINVAL;
+  if (peels_done < 0 || peels_done > RTGS_MAX_DEPTH) return RTGS_EDEPTH;
+  if (lists_bytes < rtgs_peel_list_bytes(cam->width, cam->height)) return RTGS_EWORKSPACE;
+  const int32_t tiles = rtgs_num_tiles(cam->width, cam->height);
+  const size_t slots = (size_t)tiles * RTGS_MAX_DEPTH * kTraceBlock;
+  const int32_t* idx = static_cast<const int32_t*>(lists);
+  hipLaunchKernelGGL(k_peel_start, dim3(tiles), dim3(kTraceBlock), 0, static_cast<hipStream_t>(stream), cam->width,
+                     cam->height, (cam->width + kTile - 1) / kTile, peels_done, idx,
+                     reinterpret_cast<const float*>(idx + slots) + slots, ray_start, ray_start_stride);
+  return check_launch();
 }
 
 int rtgs_render(const RtgsScene* scene, const RtgsCamera* cam, int32_t depth, float t_cutoff,

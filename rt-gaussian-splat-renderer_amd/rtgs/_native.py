@@ -24,6 +24,7 @@ TRACE_ACCUMULATE = 2
 TRACE_COMPACT = 4
 TRACE_SPLIT_ON = 8     # scheduling only: force / forbid two waves per 8x8 tile
 TRACE_SPLIT_OFF = 16
+PEEL_FRESH = 1
 
 LIB_PATH = os.environ.get("RTGS_HIP_LIB") or os.path.join(
     os.path.dirname(os.path.abspath(__file__)), "_lib", "librtgs_hip.so")
@@ -65,6 +66,12 @@ PROTOTYPES = {
                                c_void_p]),
     "rtgs_project_shard": (c_int32, [POINTER(RtgsScene), POINTER(RtgsCamera), c_int32, c_int32, c_void_p,
                                      c_size_t, c_void_p]),
+    "rtgs_peel_list_bytes": (c_size_t, [c_int32, c_int32]),
+    "rtgs_trace_lists": (c_int32, [POINTER(RtgsScene), POINTER(RtgsCamera), c_void_p, c_void_p, c_size_t, c_void_p,
+                                   c_size_t, c_int32, c_void_p]),
+    "rtgs_peel": (c_int32, [POINTER(RtgsScene), POINTER(RtgsCamera), c_void_p, c_size_t, c_int32, c_uint32, c_void_p,
+                            c_void_p, c_void_p]),
+    "rtgs_peel_start": (c_int32, [POINTER(RtgsCamera), c_void_p, c_size_t, c_int32, c_void_p, c_int32, c_void_p]),
     "rtgs_untile": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "rtgs_event_create": (c_int32, [POINTER(c_void_p)]),
     "rtgs_event_destroy": (c_int32, [c_void_p]),

@@ -41,6 +41,12 @@ class RayTracer:
         # RTGS_TILE_ORDER as in parallel.HipBackend: 0 = tile order, centre, wedge (default)
         self._order_mode = os.environ.get("RTGS_TILE_ORDER", "wedge")
         self._att_cleared = False    # clear_attenuation() ran while sample_all's per-pixel state was still owed
+        # peel lists (rtgs_trace_lists / rtgs_peel): the sample() pattern from one traversal.  RTGS_PEEL_LISTS=0:
+        # every sample() re-traverses (the K = 1 resumed launch), as up to round 3
+        self._use_lists = os.environ.get("RTGS_PEEL_LISTS", "1") != "0"
+        self._lists = None           # device buffer, rtgs_peel_list_bytes(W, H)
+        self._lists_for = None       # (scene, geometry, pose, focal) the lists were traversed for
+        self._list_peels = None      # peels of the CURRENT sample composited from the lists; None = not in step with them
 
     @property
     def attenuation_buf(self) -> torch.Tensor:
@@ -140,18 +146,77 @@ class RayTracer:
             self._att_cleared = False
             self.clear_attenuation()
 
+    # ---- peel lists -----------------------------------------------------------------------
+    def _lists_key(self, pos, rot):
+        return (id(self.scene), self.scene.geometry_key(), pos, rot, tuple(float(v) for v in self.camera.focal_length))
+
+    def _ensure_lists(self, pos, rot) -> None:
+        """Every ray's sorted distinct entries for this (geometry, pose), by ONE traversal
+        (``rtgs_trace_lists``); kept across samples while neither changes -- the reference's samples of
+        a still camera are identical (no jitter: ``random_vec3`` is unused), so is what they traverse."""
+        key = self._lists_key(pos, rot)
+        if self._lists_for == key:
+            return
+        lib = nat.lib()
+        w, h = self.buf_size.x, self.buf_size.y
+        need = lib.rtgs_peel_list_bytes(w, h)
+        if self._lists is None or self._lists.numel() < need:
+            self._lists = torch.empty(need, dtype=torch.uint8, device=self.sample_buf.device)
+        ws = self._ws()
+        pstate = (id(self.scene), self.scene.geometry_key(), ws.data_ptr(), pos, rot,
+                  tuple(float(v) for v in self.camera.focal_length))
+        projected = pstate == self._projected_for
+        self._projected_for = pstate
+        self._lists_for = None
+        nat.check(lib.rtgs_trace_lists(self.scene.native(), self.camera.native(pos, rot), nat.ptr(self._tile_order(0, 1)),
+                                       nat.ptr(self._lists), self._lists.numel(), nat.ptr(ws), ws.numel(),
+                                       1 if projected else 0, nat.stream()), "rtgs_trace_lists")
+        self._lists_for = key
+
+    def _start_from_lists(self, pos, rot) -> None:
+        """Deferred update of the ray field during / after a listed sample: generated rays of the
+        sample's pose, ``.start`` as the peels composited so far leave it (``rtgs_peel_start``)."""
+        self.camera._generate(pos, rot)
+        f = self.camera.cam_ray_field
+        nat.check(nat.lib().rtgs_peel_start(self.camera.native(pos, rot), nat.ptr(self._lists), self._lists.numel(),
+                                            int(self._state_peels), f.storage.data_ptr() + 6 * 4, nat.RAY_FLOATS,
+                                            nat.stream()), "rtgs_peel_start")
+
     # ---- the reference's API ------------------------------------------------------------
     def sample(self, depth: int):
         """Advance the current sample by one peel (ray_tracer.py:39-54).  The reference starts a
-        sample with ``clear_attenuation()`` + ``generate_ray_field()`` (90 MB of writes at 1080p);
-        here the first peel starts from registers (attenuation 1, start 0) and writes the state the
-        next peels resume from, and the rays themselves are regenerated only if somebody reads
-        them (``RayField``: lazy contents)."""
+        sample with ``clear_attenuation()`` + ``generate_ray_field()`` (90 MB of writes at 1080p) and
+        walks its BVH once per peel.  Here the first ``sample()`` for a (geometry, pose) traverses the
+        scene ONCE and keeps every ray's sorted entries (``rtgs_trace_lists``); this and the following
+        calls composite one listed entry each (``rtgs_peel``: a streaming kernel), for this sample and
+        for the next ones while scene geometry and camera stand still.  The rays and ``.start`` are
+        brought up to date only if somebody reads them (``RayField``: lazy contents).  Beyond 16 peels
+        per sample, after an edit of the ray field or of the geometry mid-sample, or with
+        RTGS_PEEL_LISTS=0, a peel is the K = 1 launch resuming from the per-pixel state."""
         first = self.num_steps == 0
+        f = self.camera.cam_ray_field
         if first:
             pos, rot = self._pose()
-            self.camera.defer_ray_field(pos, rot, lambda: self._regenerate_keeping_start(pos, rot), False)
-        self.sample_step(_fresh=first)
+            self._list_peels = None
+            if self._use_lists:
+                self._ensure_lists(pos, rot)
+                self._list_peels = 0
+                self._sample_pose = (pos, rot)
+            else:
+                self.camera.defer_ray_field(pos, rot, lambda: self._regenerate_keeping_start(pos, rot), False)
+        k = self.num_steps
+        listed = (self._list_peels == k and k < nat.MAX_DEPTH and (first or not f.edited) and
+                  self._lists_for is not None and self._lists_for[1] == self.scene.geometry_key())
+        if listed:
+            pos, rot = self._sample_pose
+            nat.check(nat.lib().rtgs_peel(self.scene.native(), self.camera.native(pos, rot), nat.ptr(self._lists),
+                                          self._lists.numel(), k, nat.PEEL_FRESH if first else 0,
+                                          nat.ptr(self.sample_buf), nat.ptr(self._attenuation), nat.stream()), "rtgs_peel")
+            self._list_peels = self._state_peels = k + 1
+            # .start (and the rays) are owed again: what a reader sees is the state after k + 1 peels
+            self.camera.defer_ray_field(pos, rot, lambda: self._start_from_lists(pos, rot), True)
+        else:
+            self.sample_step(_fresh=first and self._list_peels is None)
         self.num_steps += 1
         if self.num_steps >= depth:
             self.num_steps = 0
@@ -167,7 +232,8 @@ class RayTracer:
         rays are (``rtgs_sample_step_rays``)."""
         f = self.camera.cam_ray_field
         if f.pending and f.state_deferred:
-            f.materialise()              # peeling on after a sample_all: the state has to exist
+            f.materialise()              # peeling on after a sample_all / listed peels: the state has to exist
+        self._list_peels = None          # from here on the per-pixel state, not the lists, says where the sample is
         if f.edited:
             self.sample_step_rays()
             return

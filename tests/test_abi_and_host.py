@@ -80,6 +80,13 @@ def test_argument_validation_needs_no_gpu():
     assert lib.rtgs_frames_land(None, 1, 1, 2, 3, 4, 4, None, None, None) == -1       # n_land > batch
     cam = nat.make_camera((0, 0, 0), (0, 0, 0, 1), 64, 64, 64.0, 64.0)
     assert lib.rtgs_trace(None, cam, None, None, None, None, 1, None, 0, 0, None) == -1
+    # peel lists (ABI v6): 16 slots x (index, exponent, t1) per thread of every macro-tile
+    t = lib.rtgs_tile_size()
+    assert lib.rtgs_peel_list_bytes(1920, 1080) == lib.rtgs_num_tiles(1920, 1080) * 16 * t * t * 12
+    assert lib.rtgs_peel_list_bytes(0, 8) == 0
+    assert lib.rtgs_trace_lists(None, cam, None, None, 0, None, 0, 0, None) == -1
+    assert lib.rtgs_peel(None, cam, None, 0, 0, 0, None, None, None) == -1
+    assert lib.rtgs_peel_start(cam, None, 0, 0, None, 1, None) == -1
     with pytest.raises(ValueError):
         nat.check(-2, "depth")
     with pytest.raises(nat.RtgsError):
@@ -251,3 +258,34 @@ def test_build_is_keyed_on_the_source_hash_not_on_mtimes(tmp_path):
     assert b._stamp_ok(str(lib), ["-DRTGS_ABLATE=1"]) and not b._stamp_ok(str(lib))
     # what build() left in the tree is current: the product library without flags, the counting build with its own
     assert b._stamp_ok(b.LIB) and b._stamp_ok(b.COUNT_LIB, ["-DRTGS_COUNT=1"]) and not b._stamp_ok(b.COUNT_LIB)
+
+
+NON_DEFAULT_BUILDS = [["-DRTGS_STAMPS=1"], ["-DRTGS_COUNT=1"], ["-DRTGS_BINS=0"], ["-DRTGS_TILE_BINS=0"],
+                      ["-DRTGS_ABLATE=1"], ["-DRTGS_ABLATE=2"], ["-DRTGS_ABLATE=3"], ["-DRTGS_ABLATE=4"],
+                      ["-DRTGS_CUT_TRAVERSAL=0"], ["-DRTGS_HORIZON=0"], ["-DRTGS_LOOKAHEAD=0"], ["-DRTGS_LOOKAHEAD=2"],
+                      ["-DRTGS_TIER=4"], ["-DRTGS_BINS=0", "-DRTGS_TILE_BINS=0", "-DRTGS_STAMPS=1", "-DRTGS_COUNT=1"]]
+
+
+def test_every_remaining_kernel_switch_still_compiles():
+    # build() only compiles the default combination (+ the counting build); the diagnostic and
+    # fallback forms the tools use must not rot.  Front end + template instantiation of every instantiation for
+    # gfx950 (-fsyntax-only, ~2 s each), in parallel; the forms three rounds ruled out are gone from the source.
+    import shutil
+    import subprocess
+    from concurrent.futures import ThreadPoolExecutor
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = os.path.join(ROOT, "rt-gaussian-splat-renderer_amd", "csrc")
+
+    def check(flags):
+        out = subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "-Wno-unused-command-line-argument",
+                              "-I" + os.path.join(ROOT, "include"), "-I" + src, *flags, os.path.join(src, "rtgs_trace.hip")],
+                             capture_output=True, text=True, timeout=300)
+        return flags, out.returncode, out.stderr[-1500:]
+
+    with ThreadPoolExecutor(4) as pool:
+        for flags, rc, err in pool.map(check, NON_DEFAULT_BUILDS):
+            assert rc == 0, f"{' '.join(flags)} does not compile:\n{err}"
+    text = open(os.path.join(src, "rtgs_trace.hip")).read()
+    for gone in ("RTGS_MED3", "RTGS_TWO_LEVEL", "RTGS_SH_ABLATE", "RTGS_ABLATE_PAYLOAD", "RTGS_SKIP_LOWER", "RTGS_FAST_DIV",
+                 "RTGS_COMPOSITE_EXIT", "k_super_bbox("):
+        assert gone not in text, gone

@@ -141,6 +141,142 @@ def test_sample_called_depth_times_equals_one_pass():
     assert torch.equal(sa[fin], sb[fin])
 
 
+def _twins(arrays, cam):
+    """Two tracers on the same scene: `a` takes its peels from the lists (one traversal), `b` re-traverses for
+    every peel (the K = 1 resumed launch, RTGS_PEEL_LISTS=0)."""
+    scene, camera, a = U.build(arrays, cam)
+    _, camera_b, b = U.build(arrays, cam)
+    b._use_lists = False
+    assert a._use_lists
+    return scene, camera, a, camera_b, b
+
+
+def _same_state(a, camera, b, camera_b, tol=1e-6):
+    torch.cuda.synchronize()
+    assert float((a.sample_buf - b.sample_buf).abs().max()) <= tol
+    assert float((a.attenuation_buf - b.attenuation_buf).abs().max()) <= tol
+    sa, sb = camera.cam_ray_field.start, camera_b.cam_ray_field.start
+    assert torch.equal(torch.isfinite(sa), torch.isfinite(sb)) and torch.equal(sa[torch.isfinite(sa)], sb[torch.isfinite(sb)])
+    assert torch.equal(camera.cam_ray_field.data[..., :6], camera_b.cam_ray_field.data[..., :6])
+
+
+@pytest.mark.parametrize("name", ["oblique", "sh", "inside"])
+def test_listed_peels_equal_traversing_peels_after_every_call(name):
+    # VERDICT r3 #6: sample() x depth from ONE traversal (rtgs_trace_lists + rtgs_peel) -- the state after every
+    # single call (sample_buf, attenuation_buf, ray.start, the rays) is what the re-traversing peel leaves
+    arrays, cam, depth = U.case(name)
+    _, camera, a, camera_b, b = _twins(arrays, cam)
+    for k in range(depth):
+        a.sample(depth)
+        b.sample(depth)
+        assert a.num_steps == b.num_steps == (k + 1) % depth
+        if k in (0, 1, 5, depth - 1):
+            _same_state(a, camera, b, camera_b)
+    assert a.num_samples == b.num_samples == 1
+    lists_of = a._lists_for
+    # a second sample of the still camera: no new traversal (the lists are reused), same accumulation
+    before = a._lists.clone()
+    for _ in range(depth):
+        a.sample(depth)
+        b.sample(depth)
+    assert a._lists_for is lists_of and torch.equal(a._lists, before)
+    _same_state(a, camera, b, camera_b, tol=2e-6)
+    # against the one-pass form
+    _, _, c = U.build(arrays, cam)
+    c.sample_all(depth)
+    c.sample_all(depth)
+    torch.cuda.synchronize()
+    assert float((a.sample_buf - c.sample_buf).abs().max()) <= 4e-6
+
+
+def test_listed_peels_follow_the_camera_the_geometry_and_the_colours():
+    arrays, cam, depth = U.case("shallow")
+    scene, camera, a, camera_b, b = _twins(arrays, cam)
+    sb_scene = b.scene
+    for _ in range(depth):
+        a.sample(depth); b.sample(depth)
+    first = a._lists_for
+    # the camera moves (the viewer: clear_sample + num_steps = num_samples = 0, __main__.py:206-208)
+    for t, cm in ((a, camera), (b, camera_b)):
+        cm.position = rtgs.utils.types.vec3((0.2, -0.1, 2.8))
+        t.clear_sample(); t.num_steps = 0; t.num_samples = 0
+    for _ in range(depth):
+        a.sample(depth); b.sample(depth)
+    assert a._lists_for != first
+    _same_state(a, camera, b, camera_b)
+    # colours are read at peel time: an edit between two peels shows from the next peel on, as in the reference
+    a.sample(depth); b.sample(depth)
+    scene.color_opacity[:, :3].mul_(0.5); sb_scene.color_opacity[:, :3].mul_(0.5)
+    kept = a._lists_for
+    for _ in range(depth - 1):
+        a.sample(depth); b.sample(depth)
+    assert a._lists_for is kept                             # shading edits do not touch the lists
+    _same_state(a, camera, b, camera_b, tol=2e-6)
+    # a geometry edit mid-sample: the remaining peels traverse the NEW geometry from the state so far (the reference
+    # would too); the next sample lists anew
+    a.sample(depth); b.sample(depth)
+    scene.position.add_(0.01); sb_scene.position.add_(0.01)
+    for _ in range(depth - 1):
+        a.sample(depth); b.sample(depth)
+    _same_state(a, camera, b, camera_b, tol=2e-6)
+    for _ in range(depth):
+        a.sample(depth); b.sample(depth)
+    assert a._lists_for != kept and a._list_peels == depth
+    _same_state(a, camera, b, camera_b, tol=4e-6)
+
+
+def test_listed_peels_mix_with_direct_sample_steps_reads_and_depths_beyond_sixteen():
+    from oracle import c_oracle
+    arrays = synthetic.make_scene(2500, 1.0, 77)
+    arrays["scale"] = (arrays["scale"] * np.float32(2.0)).astype(np.float32)
+    arrays["opacity"] = (0.25 * arrays["opacity"]).astype(np.float32)
+    cam = synthetic.bench_camera(40, 36)
+    depth = 20                                              # peels 17..20 resume by traversal from the listed state
+    _, camera, a, camera_b, b = _twins(arrays, cam)
+    for k in range(depth):
+        a.sample(depth); b.sample(depth)
+        if k == 3:                                          # a reader in the middle of a sample sees the state so far
+            _same_state(a, camera, b, camera_b)
+    assert a.num_samples == 1 and a._list_peels is None     # the traversing peels took over after the 16th
+    _same_state(a, camera, b, camera_b, tol=2e-6)
+    want = c_oracle.render(arrays, cam, depth)
+    U.assert_parity(a.sample_buf.cpu().numpy().reshape(-1, 3), want, "listed depth 20")
+    # the reference's public sample_step() in the middle of a listed sample
+    a.clear_sample(); b.clear_sample()
+    for _ in range(4):
+        a.sample(16); b.sample(16)
+    a.sample_step(); b.sample_step()                        # (not counted in num_steps, as in the reference)
+    for _ in range(12):
+        a.sample(16); b.sample(16)
+    _same_state(a, camera, b, camera_b, tol=2e-6)
+    # an edited ray field: the literal per-ray path, lists or not
+    a.clear_sample(); b.clear_sample()
+    for t, cm in ((a, camera), (b, camera_b)):
+        t.sample(16)
+        cm.cam_ray_field.start[:5, :5] = 2.5
+        for _ in range(15):
+            t.sample(16)
+    _same_state(a, camera, b, camera_b, tol=2e-6)
+
+
+def test_listed_peels_with_ties_top_the_lists_up():
+    # a quarter of the Gaussians stored twice, in a frame with bins: list slots lost to twins are refilled by the
+    # wave (tie fix-up, list form), so peel k is the k-th DISTINCT entry for every ray, as in the peel loop
+    base = synthetic.make_scene(33_000, 4 / 3, 404)
+    base["scale"] = (base["scale"] * np.float32(1.5)).astype(np.float32)
+    arrays = {k: (None if v is None else np.concatenate([v, v[:9_000]])) for k, v in base.items()}
+    cam = synthetic.bench_camera(160, 120)
+    _, camera, a, camera_b, b = _twins(arrays, cam)
+    for _ in range(16):
+        a.sample(16); b.sample(16)
+    _same_state(a, camera, b, camera_b, tol=2e-6)
+    _, _, c = U.build(base, cam)
+    c.sample_all(16)
+    torch.cuda.synchronize()
+    assert float((a.sample_buf - c.sample_buf).abs().max()) <= 2e-5
+    assert float(torch.isfinite(camera.cam_ray_field.start).float().mean()) > 0.5     # full-depth rays are exercised
+
+
 def test_partial_sample_display_and_accumulation():
     arrays, cam, depth = U.case("shallow")
     _, _, tr = U.build(arrays, cam)
@@ -245,26 +381,87 @@ def test_exact_ties_do_not_use_up_peels_at_shallow_depth():
         assert np.isfinite(want["start"]).mean() > 0.2      # the full-depth case is exercised
 
 
-def test_exact_tie_at_full_depth_costs_that_pixel_one_peel():
-    # ADVICE r2 / include/rtgs_hip.h (ray_start): the documented limit of the 16-slot list.  18
-    # coaxial Gaussians, the 3rd one stored twice.  The reference composites 16 DISTINCT entry
-    # distances (#1..#16); a launch keeps the 16 nearest entries, one of them the tied twin, so it
-    # composites 15 (#1..#15) and leaves ray.start behind its list's last entry (#15), not +inf:
-    # a chained depth-17 call then goes on with #16 (16 peels in all, the reference: 17).
+def test_exact_tie_at_full_depth_still_composites_sixteen_distinct_entries():
+    # VERDICT r3 #5 (rounds 1-3 documented a limit here: 15 entries).  18 coaxial Gaussians, the 3rd one
+    # stored twice.  The reference composites 16 DISTINCT entry distances (#1..#16: scene.py:433 strict
+    # `>` after ray_tracer.py:101); a launch keeps the 16 nearest ENTRIES, one of them the tied twin --
+    # and the lane whose list came up one distinct entry short peels on inside the kernel (tie fix-up).
     n = 18
     pos = [(0, 0, -(2.0 + k)) for k in range(n)] + [(0, 0, -4.0)]
     m = len(pos)
     args = (pos, [(0.1,) * 3] * m, [(1, 1, 1)] * m, [0.1] * m)
     tr = analytic(*args, depth=16)
-    assert float(tr.sample_buf[2, 2, 0]) == pytest.approx(1 - 0.9 ** 15, abs=5e-6)
-    assert float(tr.camera.cam_ray_field.start[2, 2]) == pytest.approx(16 - math.sqrt(3) * 0.1, rel=1e-6)
-    assert float(tr.attenuation_buf[2, 2]) == pytest.approx(0.9 ** 15, abs=5e-6)
-    tr = analytic(*args, depth=17)
     assert float(tr.sample_buf[2, 2, 0]) == pytest.approx(1 - 0.9 ** 16, abs=5e-6)
     assert float(tr.camera.cam_ray_field.start[2, 2]) == pytest.approx(17 - math.sqrt(3) * 0.1, rel=1e-6)
-    # and at a shallow depth nothing is lost (the launch walks on through its 16 slots)
-    tr = analytic(*args, depth=8)
+    assert float(tr.attenuation_buf[2, 2]) == pytest.approx(0.9 ** 16, abs=5e-6)
+    tr = analytic(*args, depth=17)                      # a chain: 16 + 1, no entry lost or doubled at the seam
+    assert float(tr.sample_buf[2, 2, 0]) == pytest.approx(1 - 0.9 ** 17, abs=5e-6)
+    assert float(tr.camera.cam_ray_field.start[2, 2]) == pytest.approx(18 - math.sqrt(3) * 0.1, rel=1e-6)
+    tr = analytic(*args, depth=8)                       # shallow: the launch walks on through its 16 slots
     assert float(tr.sample_buf[2, 2, 0]) == pytest.approx(1 - 0.9 ** 8, abs=5e-6)
+    # several twins (and a triple) in one ray: 16 list slots hold 11 distinct entries, five peels are fixed up;
+    # then the ray runs out of Gaussians: 17 distinct in all, depth 16 composites 16 and depth 18 ends in a miss
+    pos = [(0, 0, -(2.0 + k)) for k in range(17)] + [(0, 0, -3.0), (0, 0, -3.0), (0, 0, -5.0), (0, 0, -7.0), (0, 0, -9.0)]
+    m = len(pos)
+    args = (pos, [(0.1,) * 3] * m, [(1, 1, 1)] * m, [0.1] * m)
+    tr = analytic(*args, depth=16)
+    assert float(tr.sample_buf[2, 2, 0]) == pytest.approx(1 - 0.9 ** 16, abs=5e-6)
+    assert float(tr.camera.cam_ray_field.start[2, 2]) == pytest.approx(17 - math.sqrt(3) * 0.1, rel=1e-6)
+    tr = analytic(*args, depth=18)
+    assert float(tr.sample_buf[2, 2, 0]) == pytest.approx(1 - 0.9 ** 17, abs=5e-6)
+    assert math.isinf(float(tr.camera.cam_ray_field.start[2, 2]))
+    # with the cut-off a fixed-up ray stops for good once it is below it
+    tr = analytic(pos, [(0.1,) * 3] * m, [(1, 1, 1)] * m, [0.5] * m, depth=16)
+    assert float(tr.attenuation_buf[2, 2]) == pytest.approx(0.5 ** 16, rel=1e-5)
+    scene_cam = U.build(dict(position=np.array(pos, np.float32), rotation=np.array([IDQ] * m, np.float32),
+                             scale=np.array([(0.1,) * 3] * m, np.float32), color=np.ones((m, 3), np.float32),
+                             opacity=np.full(m, 0.5, np.float32), sh=None), ACAM)
+    scene_cam[2].sample_all(16, t_cutoff=0.5 ** 12.5)
+    assert float(scene_cam[2].attenuation_buf[2, 2]) == pytest.approx(0.5 ** 13, rel=1e-5)   # 11 from the list + 2 fixed up
+    assert math.isinf(float(scene_cam[2].camera.cam_ray_field.start[2, 2]))
+
+
+@pytest.mark.parametrize("sh", [False, True])
+def test_ties_in_a_binned_frame_match_the_literal_peel_loop(sh):
+    # the tie fix-up on a scene large enough for the per-frame bins (>= 32 k Gaussians: the fix-up then walks the
+    # tile's own slab list), with a quarter of the Gaussians stored twice: most rays have ties among their 16
+    # nearest.  Against the reference's literal loop (NumPy fp32 + fp64) on the scene AS STORED, twins included.
+    from oracle import rtgs_ref as ref
+    base = synthetic.make_scene(33_000, 4 / 3, 404, sh=sh)
+    base["scale"] = (base["scale"] * np.float32(1.5)).astype(np.float32)
+    dup = 9_000
+    arrays = {k: (None if v is None else np.concatenate([v, v[:dup]])) for k, v in base.items()}
+    cam = synthetic.bench_camera(160, 120)
+    _, _, tr = U.build(arrays, cam)
+    tr.sample_all(16)
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(3)
+    pix = np.stack([rng.integers(0, 160, 96), rng.integers(0, 120, 96)], axis=-1)
+    osc = ref.OracleScene(**arrays)                     # fp64, twins included: strict `>` drops them
+    want = ref.render_peel(osc, cam["position"], cam["rotation"], 160, 120, cam["fx"], cam["fy"], depth=16, pixels=pix)
+    chk = ref.render_topk(ref.OracleScene(**base), cam["position"], cam["rotation"], 160, 120, cam["fx"], cam["fy"],
+                          depth=16, pixels=pix)
+    solid = ~chk["fragile"]
+    assert (want["hits"] == 16).mean() > 0.5
+    got = U.at(tr.sample_buf, pix)
+    assert np.abs(got - want["sample"])[solid].max() <= U.PIXEL_TOL
+    assert np.abs(U.at(tr.attenuation_buf, pix) - want["attenuation"])[solid].max() <= U.PIXEL_TOL
+    start = U.at(tr.camera.cam_ray_field.start, pix)
+    assert (np.isfinite(start) == np.isfinite(want["start"]))[solid].all()
+    fin = np.isfinite(want["start"]) & solid
+    assert np.abs(start - want["start"])[fin].max(initial=0.0) <= 2e-5
+    # how many pixels of the frame needed the fix-up: without it they stop one or more entries short
+    base_only = U.build(base, cam)[2]
+    base_only.sample_all(16)
+    torch.cuda.synchronize()
+    assert float((tr.sample_buf - base_only.sample_buf).abs().max()) <= 2e-5    # twins change nothing
+    # sharded and two-wave forms agree bit for bit, ties and all
+    whole = tr.sample_buf.clone()
+    for split in (nat.TRACE_SPLIT_ON, nat.TRACE_SPLIT_OFF):
+        tr.clear_sample()
+        for r in range(3):
+            tr.trace(16, tile_first=r, tile_step=3, flags=split)
+        assert torch.equal(tr.sample_buf, whole)
 
 
 @pytest.mark.parametrize("depth", [17, 24, 40])
@@ -332,7 +529,7 @@ def test_sample_all_defers_the_per_pixel_state_until_somebody_looks():
     for _ in range(2 * depth):
         b.sample(depth)
     fb = camera_b.cam_ray_field
-    assert fb.pending and not fb.state_deferred          # peels wrote .start; origin/direction are owed
+    assert fb.pending and fb.state_deferred              # listed peels: origin / direction AND .start are owed (round 4)
     torch.cuda.synchronize()
     assert float((a.sample_buf - b.sample_buf).abs().max()) <= 4e-6
     assert float((a.attenuation_buf - b.attenuation_buf).abs().max()) <= 2e-6     # first look: replayed
