@@ -43,10 +43,15 @@ HBM_PEAK_GBS = 8000.0  # MI355X spec peak, /opt/skills/guides/MI355X_MICROARCH.m
 N_SIMD = 1024
 ENGINE_CLOCK_HZ = 2.4e9
 VALU_PEAK_GINST = N_SIMD * ENGINE_CLOCK_HZ / 2 / 1e9   # G wave-instructions / s
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 MIN_TIMED_S = 0.25          # a timed batch shorter than this is repeated and the MEDIAN batch is reported
 MAX_BATCHES = 400
 LDS_BYTES_PER_INST = 256    # 64 lanes x 4 B: k_trace's LDS instructions are b32 (upper bound for its few b128 reads: x4)
+N_CU = 256
+# vector L1 (TCP): one 64-B tag access per clock per CU (MI355X_MICROARCH.md: 64 B/clk/CU) -- what the per-lane SH gathers
+# of the SH instantiations run into (TCP_TOTAL_CACHE_ACCESSES_sum, profiles/r04_c3sh_summary.json: 0.94 of this)
+L1_PEAK_GBS = N_CU * 64 * ENGINE_CLOCK_HZ / 1e9
+LDS_PEAK_GBS = N_CU * 128 * ENGINE_CLOCK_HZ / 1e9
 
 
 def parse(argv=None):
@@ -63,6 +68,9 @@ def parse(argv=None):
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo "
                     "only for functional rehearsal of the N > 1 path)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: all ranks on cuda:0")
+    ap.add_argument("--partition", default="both", choices=["both", "equal", "auto"], help="N > 1: the tile deal -- equal "
+                    "(round-robin, one gather), auto (shares calibrated on this machine, point to point), both = "
+                    "time both and report the faster verified one")
     ap.add_argument("--dist-timeout", type=float, default=300.0, help="seconds: rendezvous and every collective "
                     "(init_process_group timeout)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds the self-spawned ranks get "
@@ -234,7 +242,7 @@ def profiled_counters(cfg_name, world, src_hash):
     used when the summary carries the hash of the sources this build was made from: a counter of
     another build divided by this build's time is not a measurement."""
     path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{cfg_name}_summary.json")
-    out = {"valu": None, "lds": None, "traffic": None, "source": None, "stale": None}
+    out = {"valu": None, "lds": None, "traffic": None, "tcp": None, "ta_busy": None, "source": None, "stale": None}
     if world != 1 or not os.path.exists(path):
         return out
     with open(path) as f:
@@ -245,7 +253,11 @@ def profiled_counters(cfg_name, world, src_hash):
         return out
     t = summary.get("k_trace_hbm_bytes_per_launch")
     pmc = summary.get("kernels", {}).get("k_trace", {}).get("pmc_mean_per_launch", {})
-    out.update(valu=pmc.get("SQ_INSTS_VALU"), lds=pmc.get("SQ_INSTS_LDS"), traffic=(t["traffic_upper"] if t else None))
+    out.update(valu=pmc.get("SQ_INSTS_VALU"), lds=pmc.get("SQ_INSTS_LDS"), traffic=(t["traffic_upper"] if t else None),
+               tcp=pmc.get("TCP_TOTAL_CACHE_ACCESSES_sum"))
+    if pmc.get("TA_TA_BUSY_sum") and pmc.get("GRBM_GUI_ACTIVE"):
+        # busy cycles summed over the 256 TAs / (cycles the GPU was active, summed over the 8 XCDs / 8) / 256
+        out["ta_busy"] = pmc["TA_TA_BUSY_sum"] / N_CU / (pmc["GRBM_GUI_ACTIVE"] / 8.0)
     return out
 
 
@@ -323,68 +335,138 @@ def rank_main(args) -> int:
     cam = synthetic.bench_camera(cfg.width, cfg.height)
     scene = rtgs.Scene.from_arrays(**arrays)
     camera = rtgs.Camera(cam["position"], cam["rotation"], (cfg.width, cfg.height), (cam["fx"], cam["fy"]))
-    renderer = TileParallelRenderer(scene, camera, depth=cfg.depth, rank=rank, world=world)
-
     def sync():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        renderer.render_frame()
-    renderer.finish()
+    def verify(renderer):
+        """N > 1: consecutive frames with DIFFERENT camera poses are queued back to back through the pipeline (no
+        host synchronisation in between); what is left in the framebuffer must equal the single-rank render of the
+        LAST pose bit for bit -- for both orders of the two poses and for an odd number of frames, so that each
+        half of the ring ends a sequence (a stale or swapped half would show the other pose)."""
+        pose_a, pose_b = (0.15, -0.1, 3.0), tuple(cam["position"])
+        sequences = [(pose_a, pose_b), (pose_b, pose_a), (pose_b, pose_a, pose_b)]
+        finals, ok = [], None
+        for seq in sequences:
+            for p in seq:
+                camera.position = vec3(p)
+                renderer.render_frame()
+            renderer.finish()
+            torch.cuda.synchronize()
+            if rank == 0:
+                finals.append(renderer.framebuffer.clone())
+        if rank == 0:
+            single = TileParallelRenderer(scene, camera, depth=cfg.depth, rank=0, world=1)
+            want = {}
+            for p in (pose_a, pose_b):
+                camera.position = vec3(p)
+                single.render_frame()
+                single.finish()
+                torch.cuda.synchronize()
+                want[p] = single.framebuffer.clone()
+            ok = not torch.equal(want[pose_a], want[pose_b])
+            for seq, got in zip(sequences, finals):
+                ok = ok and bool(torch.equal(want[seq[-1]], got))
+        camera.position = vec3(cam["position"])
+        return ok
 
-    def timed_batch():
-        """EXACTLY args.steps frames between barrier + synchronize on both sides; MAX over ranks."""
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
+    def run_mode(partition):
+        """One tile deal end to end: construct (\"auto\" calibrates), warm up, the timed batches, the dominant
+        kernel alone, every rank's shard times, the verification.  Collective: every rank runs the same modes."""
+        from rtgs.parallel import _phase
+        _phase("bench: mode", partition)
+        renderer = TileParallelRenderer(scene, camera, depth=cfg.depth, rank=rank, world=world, partition=partition)
+        _phase("bench: warm-up")
+        for _ in range(args.warmup):
             renderer.render_frame()
         renderer.finish()
-        sync()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt
+        _phase("bench: timed batches")
 
-    # a frame is ~0.15 ms: K steps can be a few milliseconds, too thin a sample for one clock reading.
-    # The same K-step batch is repeated until MIN_TIMED_S has been timed (the decision uses the
-    # all-reduced time: identical on every rank) and the MEDIAN batch is the one reported.
-    batches = [timed_batch()]
-    while sum(batches) < MIN_TIMED_S and len(batches) < MAX_BATCHES:
-        batches.append(timed_batch())
-    elapsed = sorted(batches)[len(batches) // 2]
+        def timed_batch():
+            """EXACTLY args.steps frames between barrier + synchronize on both sides; MAX over ranks."""
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                renderer.render_frame()
+            renderer.finish()
+            sync()
+            dt = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([dt], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            return dt
 
-    # dominant kernel (k_trace) alone, HIP events on the launch stream, projection already done
-    reps = max(10, min(args.steps, 100))
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    renderer.trace_only()
-    torch.cuda.synchronize()
-    ev0.record()
-    for _ in range(reps):
-        renderer.trace_only()
-    ev1.record()
-    torch.cuda.synchronize()
-    trace_ms = ev0.elapsed_time(ev1) / reps
-    ev0.record()
-    for _ in range(reps):
+        # a frame is ~0.15 ms: K steps can be a few milliseconds, too thin a sample for one clock reading.
+        # The same K-step batch is repeated until MIN_TIMED_S has been timed (the decision uses the
+        # all-reduced time: identical on every rank) and the MEDIAN batch is the one reported.
+        batches = [timed_batch()]
+        while sum(batches) < MIN_TIMED_S and len(batches) < MAX_BATCHES:
+            batches.append(timed_batch())
+        elapsed = sorted(batches)[len(batches) // 2]
+
+        # dominant kernel (k_trace) alone, HIP events on the launch stream, projection already done
+        _phase("bench: kernel timings")
+        reps = max(10, min(args.steps, 100))
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         renderer.project_only()
-    ev1.record()
-    torch.cuda.synchronize()
-    project_ms = ev0.elapsed_time(ev1) / reps
-    # every rank's shard trace and projection (ms), so that imbalance between the ranks is visible
-    per_rank = None
+        renderer.trace_only()
+        torch.cuda.synchronize()
+        ev0.record()
+        for _ in range(reps):
+            renderer.trace_only()
+        ev1.record()
+        torch.cuda.synchronize()
+        trace_ms = ev0.elapsed_time(ev1) / reps
+        ev0.record()
+        for _ in range(reps):
+            renderer.project_only()
+        ev1.record()
+        torch.cuda.synchronize()
+        project_ms = ev0.elapsed_time(ev1) / reps
+        # every rank's shard trace and projection (ms), so that imbalance between the ranks is visible
+        per_rank = None
+        if world > 1:
+            rows = [None] * world
+            dist.all_gather_object(rows, {"rank": rank, "local_tiles": renderer.local_tiles,
+                                          "trace_ms": trace_ms, "project_ms": project_ms})
+            per_rank = {"trace_ms": [r["trace_ms"] for r in rows], "project_ms": [r["project_ms"] for r in rows],
+                        "local_tiles": [r["local_tiles"] for r in rows]}
+            for k in ("trace_ms", "project_ms"):
+                per_rank[k + "_min"], per_rank[k + "_max"] = min(per_rank[k]), max(per_rank[k])
+        _phase("bench: verify")
+        verified = verify(renderer) if world > 1 else None
+        _phase("bench: mode done", verified)
+        return dict(renderer=renderer, batches=batches, elapsed=elapsed, trace_ms=trace_ms, project_ms=project_ms,
+                    per_rank=per_rank, verified=verified, partition=renderer.partition.name,
+                    shares=renderer.partition.shares(), calibration=renderer.calibration)
+
+    # N > 1: the equal round-robin deal (one dist.gather), then the link-aware deal calibrated on this machine
+    # (unequal shares, point to point); the line reports the faster of the VERIFIED ones, `secondary.partitions` both
+    modes = ["equal"] if world == 1 else {"both": ["equal", "auto"], "equal": ["equal"], "auto": ["auto"]}[args.partition]
+    runs = {}
+    for mode in modes:
+        try:
+            runs[mode] = run_mode(mode)
+        except Exception as exc:                       # (a deal that cannot run must not take the other one's number with it)
+            if mode == modes[0] and len(modes) == 1:
+                raise
+            print(f"bench.py rank {rank}: partition {mode!r} failed: {exc!r}", file=sys.stderr)
+            runs[mode] = None
+    choice = [None]
+    if rank == 0:
+        ok = {m: r for m, r in runs.items() if r is not None and (world == 1 or r["verified"])}
+        pool = ok or {m: r for m, r in runs.items() if r is not None}
+        choice = [min(pool, key=lambda m: pool[m]["elapsed"]) if pool else None]
     if world > 1:
-        rows = [None] * world
-        dist.all_gather_object(rows, {"rank": rank, "local_tiles": renderer.local_tiles,
-                                      "trace_ms": trace_ms, "project_ms": project_ms})
-        per_rank = {"trace_ms": [r["trace_ms"] for r in rows], "project_ms": [r["project_ms"] for r in rows],
-                    "local_tiles": [r["local_tiles"] for r in rows]}
-        for k in ("trace_ms", "project_ms"):
-            per_rank[k + "_min"], per_rank[k + "_max"] = min(per_rank[k]), max(per_rank[k])
+        dist.broadcast_object_list(choice, src=0)
+    if choice[0] is None or runs.get(choice[0]) is None:
+        raise SystemExit("bench.py: no tile deal ran to completion")
+    best = runs[choice[0]]
+    renderer, batches, elapsed = best["renderer"], best["batches"], best["elapsed"]
+    trace_ms, project_ms, per_rank, verified = best["trace_ms"], best["project_ms"], best["per_rank"], best["verified"]
 
     # SURVEY 8(d) secondary figures: per-frame HIP-event times (median of 30 frames, first launch
     # to framebuffer complete) and closest-hit queries/s = depth x rays/s
@@ -406,38 +488,6 @@ def rank_main(args) -> int:
         frame_ms_median = sorted(a_.elapsed_time(b_) for a_, b_ in evs)[len(evs) // 2]
         one.close()
 
-    # N > 1: consecutive frames with DIFFERENT camera poses are queued back to back through the
-    # double-buffered pipeline (no host synchronisation in between); what is left in the
-    # framebuffer must equal the single-rank render of the LAST pose bit for bit -- for both
-    # orders of the two poses and for an odd number of frames, so that each half of the double
-    # buffer ends a sequence (a stale or swapped half would show the other pose)
-    verified = None
-    if world > 1:
-        pose_a, pose_b = (0.15, -0.1, 3.0), tuple(cam["position"])
-        sequences = [(pose_a, pose_b), (pose_b, pose_a), (pose_b, pose_a, pose_b)]
-        finals = []
-        for seq in sequences:
-            for p in seq:
-                camera.position = vec3(p)
-                renderer.render_frame()
-            renderer.finish()
-            torch.cuda.synchronize()
-            if rank == 0:
-                finals.append(renderer.framebuffer.clone())
-        if rank == 0:
-            single = TileParallelRenderer(scene, camera, depth=cfg.depth, rank=0, world=1)
-            want = {}
-            for p in (pose_a, pose_b):
-                camera.position = vec3(p)
-                single.render_frame()
-                single.finish()
-                torch.cuda.synchronize()
-                want[p] = single.framebuffer.clone()
-            verified = not torch.equal(want[pose_a], want[pose_b])
-            for seq, got in zip(sequences, finals):
-                verified = verified and bool(torch.equal(want[seq[-1]], got))
-        camera.position = vec3(cam["position"])
-
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         mrays = cfg.rays / (elapsed / args.steps) / 1e6
@@ -447,8 +497,21 @@ def rank_main(args) -> int:
         src_hash, count_lib = source_hash()
         pc = profiled_counters(cfg.name, world, src_hash)
         valu, traffic = pc["valu"], pc["traffic"]
-        achieved = valu / (trace_ms * 1e-3) / 1e9 if valu else None
-        hbm_gbs = traffic / (trace_ms * 1e-3) / 1e9 if traffic else None
+        t_k = trace_ms * 1e-3
+        achieved = valu / t_k / 1e9 if valu else None
+        hbm_gbs = traffic / t_k / 1e9 if traffic else None
+        l1_gbs = pc["tcp"] * 64 / t_k / 1e9 if pc["tcp"] else None
+        lds_gbs = pc["lds"] * LDS_BYTES_PER_INST / t_k / 1e9 if pc["lds"] else None
+        # the bound reported is the resource with the highest fraction of its peak IN THIS CONFIG: the
+        # no-SH instantiations issue VALU instructions, the SH ones wait for the vector L1's tag pipeline
+        fractions = {"valu": (achieved / VALU_PEAK_GINST) if achieved else None,
+                     "vmem-L1": (l1_gbs / L1_PEAK_GBS) if l1_gbs else None,
+                     "lds": (lds_gbs / LDS_PEAK_GBS) if lds_gbs else None,
+                     "hbm": (hbm_gbs / HBM_PEAK_GBS) if hbm_gbs else None}
+        known = {k: v for k, v in fractions.items() if v is not None}
+        bound = max(known, key=known.get) if known else "valu"
+        by_bound = {"valu": (achieved, VALU_PEAK_GINST, "G wave64-instr/s"), "vmem-L1": (l1_gbs, L1_PEAK_GBS, "GB/s"),
+                    "lds": (lds_gbs, LDS_PEAK_GBS, "GB/s"), "hbm": (hbm_gbs, HBM_PEAK_GBS, "GB/s")}[bound]
         # SURVEY 8(d) honesty columns (ii) and (iii): tests actually executed vs rays x N, LDS bytes/s
         counts = None
         if world == 1 and os.path.exists(count_lib):
@@ -457,7 +520,7 @@ def rank_main(args) -> int:
             except Exception as exc:   # the honesty columns must never break the headline
                 counts = {"error": repr(exc)}
         tests = counts.get("tests_executed") if counts else None
-        lds_bps = pc["lds"] * LDS_BYTES_PER_INST / (trace_ms * 1e-3) if pc["lds"] else None
+        lds_bps = lds_gbs * 1e9 if lds_gbs else None
         base_metric = "Mrays/s at 1920x1080, 100k Gaussians; achieved HBM GB/s vs peak"
         metric = base_metric if (cfg.width, cfg.height, cfg.n) == (1920, 1080, 100_000) else \
             f"Mrays/s at {cfg.width}x{cfg.height}, {cfg.n} Gaussians; achieved HBM GB/s vs peak"
@@ -465,6 +528,7 @@ def rank_main(args) -> int:
         if world > 1:
             comm = " + RCCL gather" if args.backend == "nccl" else f" + {args.backend} gather (rehearsal, not RCCL)"
             comm += f", {renderer.frames_in_flight} frames in flight per rank, {renderer.gather_batch} per gather"
+            comm += f", tile deal: {best['partition']}"
         line = {
             "metric": metric,
             "value": mrays, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
@@ -483,9 +547,12 @@ def rank_main(args) -> int:
             # issue rate.  achieved = SQ_INSTS_VALU per launch (committed profile of THIS source
             # hash and config, else null) / the kernel time measured live here with HIP events on
             # the launch stream.
-            "roofline": {"bound": "valu", "kernel": "k_trace", "achieved": achieved,
-                         "peak": VALU_PEAK_GINST, "unit": "G wave64-instr/s",
-                         "frac": (achieved / VALU_PEAK_GINST) if achieved else None,
+            "roofline": {"bound": bound, "kernel": "k_trace", "achieved": by_bound[0],
+                         "peak": by_bound[1], "unit": by_bound[2],
+                         "frac": known.get(bound), "fractions": fractions,
+                         "valu_achieved_ginst": achieved, "valu_peak_ginst": VALU_PEAK_GINST,
+                         "l1_achieved_gbs": l1_gbs, "l1_peak_gbs": L1_PEAK_GBS, "ta_busy_frac": pc["ta_busy"],
+                         "tcp_cache_accesses_per_launch": pc["tcp"],
                          "traffic": traffic, "traffic_unit": "HBM bytes per k_trace launch (PMC)",
                          "hbm_achieved_gbs": hbm_gbs, "hbm_peak_gbs": HBM_PEAK_GBS,
                          "hbm_frac": (hbm_gbs / HBM_PEAK_GBS) if hbm_gbs else None,
@@ -499,7 +566,10 @@ def rank_main(args) -> int:
                          "tests_per_s": (tests / (trace_ms * 1e-3)) if tests else None,
                          "counts": counts,
                          "lds_bytes_per_s": lds_bps, "lds_insts_per_launch": pc["lds"],
-                         "note": "frac = VALU wave-instructions issued / (1024 SIMDs x 2.4 GHz / 2); null when the "
+                         "note": "bound = the resource with the highest fraction of its peak among fractions{}: valu = "
+                                 "SQ_INSTS_VALU / (1024 SIMDs x 2.4 GHz / 2); vmem-L1 = TCP_TOTAL_CACHE_ACCESSES_sum x 64 B / "
+                                 "(256 CUs x 64 B/clk x 2.4 GHz); lds = SQ_INSTS_LDS x 256 B / (256 CUs x 128 B/clk x 2.4 GHz); "
+                                 "hbm = (FETCH_SIZE x 2 + WRITE_SIZE) / 8 TB/s; all null when the "
                                  "committed counters are of another source hash.  speedup_vs_streamed_model = "
                                  "SURVEY 8(d)'s every-tile-streams-every-Gaussian byte count / kernel time / 8 TB/s: "
                                  "not a roofline fraction, the kernel culls that stream instead of performing it.  "
@@ -531,6 +601,13 @@ def rank_main(args) -> int:
             line["verified"] = verified
         if per_rank is not None:
             line["per_rank"] = per_rank
+        if world > 1:
+            line["secondary"]["partitions"] = {
+                m: (None if r is None else {"ms_per_step": r["elapsed"] / args.steps * 1e3, "verified": r["verified"],
+                                            "deal": r["partition"], "shares": r["shares"], "calibration": r["calibration"],
+                                            "per_rank_trace_ms": r["per_rank"]["trace_ms"]})
+                for m, r in runs.items()}
+            line["secondary"]["partition_reported"] = choice[0]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, arrays, cam, args.cpu_rays)
         print(json.dumps(line), flush=True)

@@ -90,6 +90,8 @@ typedef struct RtgsCamera {
  * that launches of few tiles (small shards) get by default */
 #define RTGS_TRACE_SPLIT_ON 8u
 #define RTGS_TRACE_SPLIT_OFF 16u
+#define RTGS_TRACE_TILE_LIST 32u  /* the shard is tile_list[0 .. tile_count) (ABI v6), not (tile_first, tile_step);
+                                     tile_count = 0 (an empty share) renders nothing */
 
 typedef struct RtgsTraceParams {
   int32_t depth;        /* peels performed by this call, >= 1.  Above RTGS_MAX_DEPTH the call  */
@@ -105,6 +107,11 @@ typedef struct RtgsTraceParams {
                            only: the image and the compact layout do not depend on it.  Work-
                            groups b and b + 256 share a CU on MI355X, so an order that sorts the
                            tiles by expected cost gives every CU a mix of heavy and light tiles. */
+  const int32_t* tile_list;  /* with RTGS_TRACE_TILE_LIST (ABI v6): DEVICE array of tile_count macro-tile ids, the shard
+                           is exactly these tiles -- any partition of the frame, e.g. unequal shares per rank
+                           (rtgs.parallel.Partition) -- and local tile l (compact slot l, tile_order's index) is
+                           tile_list[l]; tile_first / tile_step are ignored.  Must be NULL without the flag. */
+  int32_t tile_count;
 } RtgsTraceParams;
 
 int rtgs_abi_version(void);
@@ -157,6 +164,9 @@ int32_t rtgs_num_local_tiles(int32_t width, int32_t height, int32_t tile_first, 
  *           0.310 -> 0.289).  What rtgs.RayTracer and the tile-parallel renderer use. */
 int32_t rtgs_launch_order(int32_t width, int32_t height, int32_t tile_first, int32_t tile_step, int32_t kind,
                           int32_t* order);
+/* the same for an explicit tile list (HOST array, what RtgsTraceParams.tile_list will hold on the device) */
+int32_t rtgs_launch_order_list(int32_t width, int32_t height, const int32_t* tiles, int32_t n_tiles, int32_t kind,
+                               int32_t* order);
 
 /* RayTracer.sample_step x depth (ray_tracer.py:39-54, 79-104) with Scene.hit's closest-hit
  * semantics (scene.py:433-437), Gaussian.hit (gaussian.py:203-230), Gaussian.eval / eval_sh
@@ -256,6 +266,18 @@ int rtgs_shard_frame(const RtgsScene* scene, const RtgsCamera* cam, const RtgsTr
  * rtgs_untile.  n_land = 0 (ranks that are not the destination): only the event. */
 int rtgs_frames_land(const float* gathered, int32_t world, int32_t tiles_per_rank, int32_t batch, int32_t n_land,
                      int32_t width, int32_t height, float* const* images, rtgs_stream_t stream, void* sent_event);
+
+/* The landing side for ANY partition of the frame (ABI v6; RtgsTraceParams.tile_list on the rendering side):
+ * rank r's buffer rank_bufs[r] (HOST array of `world` <= 16 device pointers; the destination's own shard
+ * is read where it was traced) holds `batch` frames of rank_tiles[r] (HOST array) compact tiles each,
+ * [frame][slot][T][T][3]; tile_map (DEVICE, one int32 per macro-tile of the frame) = rank << 24 | slot.
+ * rtgs_frames_land_map is rtgs_frames_land (event, then the first n_land frames scattered into images),
+ * rtgs_untile_map one frame without the event. */
+int rtgs_frames_land_map(const float* const* rank_bufs, const int32_t* rank_tiles, int32_t world, const int32_t* tile_map,
+                         int32_t batch, int32_t n_land, int32_t width, int32_t height, float* const* images,
+                         rtgs_stream_t stream, void* sent_event);
+int rtgs_untile_map(const float* const* rank_bufs, const int32_t* rank_tiles, int32_t world, const int32_t* tile_map,
+                    int32_t width, int32_t height, float* image, rtgs_stream_t stream);
 
 /* Scene.hit (scene.py:406-450) for a batch of arbitrary rays: brute-force closest hit,
  * argmin t1 subject to ray.start < t1 < ray.end; lowest index wins exact ties.

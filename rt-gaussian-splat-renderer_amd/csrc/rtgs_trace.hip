@@ -120,6 +120,18 @@ namespace {
 #define RTGS_TIER 8       // insertions touch only the first RTGS_TIER slots while slot RTGS_TIER-1 is empty in every lane
 #endif                    // (best of 4 / 6 / 8 / 10 / 12; without the tiers c3 0.1634 -> 0.1545 ms)
 
+#ifndef RTGS_SH_STAGE
+#define RTGS_SH_STAGE 0   // 1: SH instantiations stage the coefficients of a list position's distinct Gaussians in LDS once per
+#endif                    // WAVE (LDS-DMA) and read them per lane from there, instead of 64 lanes x 12 gathers.  Same pixels bit
+                          // for bit (GPU suite green with it), but SLOWER as built: c3 + SH 0.291 -> 0.325 ms, c5 1.282 -> 1.713
+                          // (round 4): the gather's bound (vector-L1 tag rate) goes away and a serial chain
+                          // per list position -- exact dedupe loop, DMA latency, four LDS round trips -- takes its place; the
+                          // remedies (staging a wave's ~30 distinct Gaussians once, or two positions in flight) need 6-8 KB of
+                          // LDS per wave, which costs the 1 M-Gaussian form a workgroup per CU
+#ifndef RTGS_SH_FMA
+#define RTGS_SH_FMA 0     // 1: the one-pass gather folds the coefficients in with explicit fmaf chains (sh_add) instead of
+#endif                    // `+=` that the compiler contracts as it likes: c3 + SH 0.291 -> 0.301 ms, c5 1.303 -> 1.542 (141 VGPRs,
+                          // 3 waves per SIMD; 1.323 capped at 128 with 7 spilled); the `+=` form compiles to 127 VGPRs
 #ifndef RTGS_SLAB_ITERS
 #define RTGS_SLAB_ITERS 2
 #endif
@@ -217,6 +229,8 @@ struct TraceArgs {
   int32_t width, height;
   int32_t tiles_x;
   int32_t tile_first, tile_step;
+  const int32_t* tile_list;   // optional: local tile l is macro-tile tile_list[l] (any partition of the frame), else tile_first + l * tile_step
+  int32_t total_tiles;
   int32_t depth;
   float t_cutoff;
   uint32_t flags;
@@ -875,6 +889,17 @@ __device__ __forceinline__ unsigned pair_eval(const float4* __restrict__ rec, co
 // compositing loop will; if every ray of the tile is below the cut-off there -- or already holds
 // `depth` final entries -- a wave ballot skips the rest of the round.  Exact: a terminated ray
 // composites nothing behind those entries, so the image equals the compositing-only cut-off's.
+// colour += sum_q Y_q * sh_q (gaussian.py:165-181) in explicit fma chains: the single-entry paths (listed peel, tie
+// fix-up, single peel).  The one-pass list's gather keeps its `+=` form (RTGS_SH_FMA): within 1 ulp per term of this
+__device__ __forceinline__ void sh_add(float4& co, const float (&Y)[RTGS_SH_COEFFS], const float* __restrict__ sp) {
+#pragma unroll
+  for (int q = 0; q < RTGS_SH_COEFFS; ++q) {
+    co.x = fmaf(Y[q], sp[3 * q + 0], co.x);
+    co.y = fmaf(Y[q], sp[3 * q + 1], co.y);
+    co.z = fmaf(Y[q], sp[3 * q + 2], co.z);
+  }
+}
+
 // kList (rtgs_trace_lists): the launch stores every ray's sorted distinct entries instead of compositing them
 // (an instantiation of its own: as a run-time branch it cost the main one five spilled VGPRs).
 template <bool kHasSh, bool kBig, int kK, int kSplit, bool kCut = false, bool kList = false>
@@ -915,7 +940,18 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   // surviving slab ids: 16 bits are enough below kBigSceneSlabs (4 096) slabs
   using SlabId = typename std::conditional<kBig, int, unsigned short>::type;
   static_assert(kBig || kBigSceneSlabs <= 65536, "slab ids of small scenes are stored in 16 bits");
-  __shared__ SlabId s_slab[kSlabCap];
+  // SH staging (kStage): kStageSlots x 48 floats per compositing wave, in the LDS that is idle by then -- the slab
+  // list and the group list are dead once a tile's last round of expansion is behind its barrier (the waves
+  // that are still tracing only read the survivor list) -- topped up to 12 KB for the small-scene forms
+  constexpr bool kStage = RTGS_SH_STAGE != 0 && kHasSh && kK == RTGS_MAX_DEPTH;
+  constexpr int kStageSlots = 16, kStageStride = 48;
+  constexpr int kStageBytes = kWavesPerTile * kStageSlots * kStageStride * (int)sizeof(float);
+  constexpr int kSlabBytes = (kSlabCap * (int)sizeof(SlabId) + 15) & ~15;
+  constexpr int kSuperInts = (kBig ? TN::kSlabIters * kBlock : 1);
+  constexpr int kMiscBytes = kSlabBytes + kSuperInts * 4 > kStageBytes ? kSlabBytes + kSuperInts * 4 : kStageBytes;
+  __shared__ float4 s_misc[kStage ? kMiscBytes / 16 + 1 : 1];
+  __shared__ SlabId s_slab_own[kStage ? 1 : kSlabCap];
+  SlabId* const s_slab = kStage ? reinterpret_cast<SlabId*>(s_misc) : s_slab_own;
   // depth keys of the first kSortMax listed slabs: only alive between the scan and the sort, when
   // the survivor pool is idle (every batch ends with a barrier) -- they share its LDS
   constexpr int kSortMax = RTGS_SORT_MAX < kListCap ? RTGS_SORT_MAX : kListCap;   // kListCap floats fit the pool
@@ -929,7 +965,9 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   __shared__ int s_rcnt[kRegions], s_rmore[kRegions];
   constexpr int kSuperStep = kSlabIters * kBlock;   // slab groups scanned per outer step
   constexpr bool kTwo = kBig;   // two-level slab scan (small scenes: c3 0.260 vs 0.261 ms flat, one barrier more)
-  __shared__ int s_super[kTwo ? kSuperStep : 1];
+  static_assert(kSuperInts == (kTwo ? kSuperStep : 1), "group list size");
+  __shared__ int s_super_own[kStage ? 1 : kSuperInts];
+  int* const s_super = kStage ? reinterpret_cast<int*>(reinterpret_cast<char*>(s_misc) + kSlabBytes) : s_super_own;
   __shared__ int s_wcnt2[2][kWaves];
 
   const int tid = threadIdx.x;
@@ -937,7 +975,8 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tile bounds stay in SGPRs
   const int ltile = a.tile_order ? a.tile_order[blockIdx.x] : (int)blockIdx.x;
   if ((unsigned)ltile >= gridDim.x) return;   // a malformed caller-supplied order must not write out of bounds
-  const int tile = a.tile_first + ltile * a.tile_step;
+  const int tile = a.tile_list ? a.tile_list[ltile] : a.tile_first + ltile * a.tile_step;
+  if ((unsigned)tile >= (unsigned)a.total_tiles) return;   // (a malformed caller-supplied list)
   const int mi0 = (tile % a.tiles_x) * kTile;
   const int mj0 = (tile / a.tiles_x) * kTile;
   const int sub = wave % kWavesPerTile;    // which 8x8 tile of the macro-tile
@@ -1559,7 +1598,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
     const int32_t* tbl = nullptr;
     int nlist = nsl;
     if constexpr (RTGS_TILE_BINS != 0) {
-      const int tile_f = ea->tile_first + ltile * ea->tile_step;
+      const int tile_f = ea->tile_list ? ea->tile_list[ltile] : ea->tile_first + ltile * ea->tile_step;
       const int bin_f = ((tile_f / ea->tiles_x) >> ea->bin_shift) * ea->bin_sx + ((tile_f % ea->tiles_x) >> ea->bin_shift);
       if (ea->tile_bin && ea->bin_count && __builtin_amdgcn_readfirstlane(ea->bin_count[bin_f]) >= 0) {
         const int32_t* const tb = ea->tile_bin + (size_t)tile_f * kTileBinCap;
@@ -1610,7 +1649,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
       // peel lists, [tile][slot][thread], for rtgs_peel to composite one per call (the reference viewer's
       // sample() pattern, __main__.py:253-256: 16 calls, ONE traversal).  A tied twin is dropped here, and a
       // full list that came up short that way is topped up by the wave (the tie fix-up, list form).
-      const int tile_l = ea->tile_first + ltile * ea->tile_step;
+      const int tile_l = ea->tile_list ? ea->tile_list[ltile] : ea->tile_first + ltile * ea->tile_step;
       const size_t lbase = (size_t)tile_l * (kK * kTraceBlock) + (size_t)(sub * kWave + lane_e);
       int cnt = 0;
       unsigned prev = 0u;
@@ -1731,12 +1770,71 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
             // c5 1.306 -> 1.122 -- the bound of staging a wave's distinct Gaussians in LDS; but the
             // 192 B per staged Gaussian cost a workgroup per CU beyond ~20 per wave, and with one
             // workgroup less the same builds run at 0.281 / 1.385: nothing left.)
+            if constexpr (!kStage) {
+#if RTGS_SH_FMA
+            sh_add(co, Ysh, sh + (size_t)gi * (RTGS_SH_COEFFS * 3));
+#else
             const float* sp = sh + (size_t)gi * (RTGS_SH_COEFFS * 3);
 #pragma unroll
             for (int q = 0; q < RTGS_SH_COEFFS; ++q) {
               co.x += Ysh[q] * sp[3 * q + 0];
               co.y += Ysh[q] * sp[3 * q + 1];
               co.z += Ysh[q] * sp[3 * q + 2];
+            }
+#endif
+            }
+          }
+          if constexpr (kStage) {
+            // Round 4: the gather above is bound by the vector L1's tag rate -- 64 lanes x 12 loads per entry, ~25
+            // line accesses per load (the TCP coalesces inside quarter-waves only): TCP_TOTAL_CACHE_ACCESSES at
+            // 0.94 of one per clock per CU on c3 + SH (profiles/r04_c3sh_summary.json) -- for ~12 distinct
+            // Gaussians among the 64 lanes of a list position.  So the WAVE fetches each distinct Gaussian's 45
+            // coefficients once, straight into LDS (global_load_lds: lane q < 45 brings coefficient q, 3 lines,
+            // no VGPRs), and every lane reads its own Gaussian's from there; same values, same order of
+            // operations: pixels unchanged bit for bit.  Exact dedupe: the first pending lane's Gaussian is
+            // broadcast, the lanes that hold it take the slot, repeat (a position with more than kStageSlots
+            // distinct Gaussians takes another pass).
+            float* const stg = reinterpret_cast<float*>(s_misc) + sub * (kStageSlots * kStageStride);
+            bool want = live;
+            unsigned long long pend = __builtin_amdgcn_ballot_w64(want);
+            while (pend) {
+              // (the previous position's reads of the slots are complete before they are written again)
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+              unsigned long long todo = pend;
+              int nslot = 0, slot_l = -1;
+              while (todo && nslot < kStageSlots) {
+                const unsigned gl = (unsigned)__builtin_amdgcn_readlane((int)gi, __builtin_ctzll(todo));
+                const bool mine = want && gi == gl;
+                slot_l = mine ? nslot : slot_l;
+                if (lane_e < RTGS_SH_COEFFS * 3)
+                  __builtin_amdgcn_global_load_lds(
+                      (const __attribute__((address_space(1))) void*)(sh + (size_t)gl * (RTGS_SH_COEFFS * 3) + lane_e),
+                      (__attribute__((address_space(3))) void*)(stg + nslot * kStageStride), 4, 0, 0);
+                todo &= ~__builtin_amdgcn_ballot_w64(mine);
+                ++nslot;
+              }
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              if (slot_l >= 0) {
+                // four steps of 12 floats (4 coefficients x rgb): all 48 in flight at once cost the c5 instantiation
+                // 34 VGPRs and a wave per SIMD
+                const float4* lp = reinterpret_cast<const float4*>(stg + slot_l * kStageStride);
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                  const float4 v0 = lp[3 * c4], v1 = lp[3 * c4 + 1], v2 = lp[3 * c4 + 2];
+                  const float cf[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) {
+                    if (4 * c4 + q < RTGS_SH_COEFFS) {
+                      co.x = fmaf(Ysh[4 * c4 + q], cf[3 * q + 0], co.x);
+                      co.y = fmaf(Ysh[4 * c4 + q], cf[3 * q + 1], co.y);
+                      co.z = fmaf(Ysh[4 * c4 + q], cf[3 * q + 2], co.z);
+                    }
+                  }
+                  asm volatile("" ::: "memory");   // (keeps the next step's reads behind this step's arithmetic)
+                }
+                want = false;
+              }
+              pend = __builtin_amdgcn_ballot_w64(want);
             }
           }
         }
@@ -1779,13 +1877,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
           if (lane == fl) {
             float4 co = colop[gmin];
             if (kHasSh) {
-              const float* sp = sh + (size_t)gmin * (RTGS_SH_COEFFS * 3);
-#pragma unroll
-              for (int q = 0; q < RTGS_SH_COEFFS; ++q) {
-                co.x += Ysh[q] * sp[3 * q + 0];
-                co.y += Ysh[q] * sp[3 * q + 1];
-                co.z += Ysh[q] * sp[3 * q + 2];
-              }
+              sh_add(co, Ysh, sh + (size_t)gmin * (RTGS_SH_COEFFS * 3));
             }
             const float alpha = co.w * exp_m3(wk);
             const float wa = T * alpha;
@@ -1901,13 +1993,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_peel(const PeelArgs a, const fl
     const float in = 1.0f / sqrtf(wx * wx + wy * wy + wz * wz);  // gaussian.py:200
     float Ysh[RTGS_SH_COEFFS];
     sh_basis(wx * in, wy * in, wz * in, Ysh);
-    const float* sp = sh + (size_t)gi * (RTGS_SH_COEFFS * 3);
-#pragma unroll
-    for (int q = 0; q < RTGS_SH_COEFFS; ++q) {
-      co.x += Ysh[q] * sp[3 * q + 0];
-      co.y += Ysh[q] * sp[3 * q + 1];
-      co.z += Ysh[q] * sp[3 * q + 2];
-    }
+    sh_add(co, Ysh, sh + (size_t)gi * (RTGS_SH_COEFFS * 3));
   }
   const float alpha = co.w * exp_m3(wk);
   const float wa = T * alpha;
@@ -1948,6 +2034,21 @@ __global__ __launch_bounds__(256) void k_untile(const float* __restrict__ compac
   const int rank = tile % world, local = tile / world;
   const float* s = compact + (((size_t)rank * rank_stride + local) * kTile * kTile +
                               (size_t)(i % kTile) * kTile + (j % kTile)) * 3;
+  float* o = image + (size_t)p * 3;
+  o[0] = s[0]; o[1] = s[1]; o[2] = s[2];
+}
+
+// Any partition of the frame (rtgs.parallel.Partition): tile_map[tile] = rank << 24 | compact slot in that rank's
+// buffer; every rank has a buffer of its own (the destination's own shard is read where it was traced: no copy).
+constexpr int kMaxRanks = 16;
+struct RankBufs { const float* p[kMaxRanks]; };
+__global__ __launch_bounds__(256) void k_untile_map(RankBufs bufs, const int32_t* __restrict__ tile_map, int width,
+                                                     int height, int tiles_x, float* __restrict__ image) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= width * height) return;
+  const int i = p / height, j = p % height;
+  const int m = tile_map[(j / kTile) * tiles_x + i / kTile];
+  const float* s = bufs.p[m >> 24] + ((size_t)(m & 0xFFFFFF) * kTile * kTile + (size_t)(i % kTile) * kTile + (j % kTile)) * 3;
   float* o = image + (size_t)p * 3;
   o[0] = s[0]; o[1] = s[1]; o[2] = s[2];
 }
@@ -2035,14 +2136,13 @@ int32_t rtgs_num_local_tiles(int32_t width, int32_t height, int32_t tile_first, 
 }
 
 // Host only.  kind 0: most central tile first; kind 1: one image wedge per XCD (see rtgs_hip.h).
-int32_t rtgs_launch_order(int32_t width, int32_t height, int32_t tile_first, int32_t tile_step, int32_t kind,
-                          int32_t* order) {
-  const int32_t n = rtgs_num_local_tiles(width, height, tile_first, tile_step);
+static int32_t launch_order_of(int32_t width, int32_t height, const std::vector<int32_t>& tiles, int32_t kind, int32_t* order) {
+  const int32_t n = (int32_t)tiles.size();
   if (!order || n <= 0 || (kind != 0 && kind != 1)) return RTGS_EINVAL;
   const int tx = (width + kTile - 1) / kTile;
   std::vector<double> centr(n), angle(n);
   for (int32_t l = 0; l < n; ++l) {
-    const int t = tile_first + l * tile_step;
+    const int t = tiles[l];
     const double cx = ((t % tx) + 0.5) * kTile - 0.5 * width, cy = ((t / tx) + 0.5) * kTile - 0.5 * height;
     centr[l] = std::max(std::fabs(cx) / (0.5 * width), std::fabs(cy) / (0.5 * height));
     angle[l] = std::atan2(cy, cx);
@@ -2070,6 +2170,26 @@ int32_t rtgs_launch_order(int32_t width, int32_t height, int32_t tile_first, int
     for (int x = 0; x < kXcds; ++x)
       if (i < wedge[x].size()) order[pos++] = wedge[x][i];
   return pos;
+}
+
+int32_t rtgs_launch_order(int32_t width, int32_t height, int32_t tile_first, int32_t tile_step, int32_t kind,
+                          int32_t* order) {
+  const int32_t n = rtgs_num_local_tiles(width, height, tile_first, tile_step);
+  if (n <= 0) return RTGS_EINVAL;
+  std::vector<int32_t> tiles(n);
+  for (int32_t l = 0; l < n; ++l) tiles[l] = tile_first + l * tile_step;
+  return launch_order_of(width, height, tiles, kind, order);
+}
+
+// the same for an explicit tile list (HOST array): RtgsTraceParams.tile_list's launch order
+int32_t rtgs_launch_order_list(int32_t width, int32_t height, const int32_t* tiles, int32_t n_tiles, int32_t kind,
+                               int32_t* order) {
+  if (!tiles || n_tiles <= 0) return RTGS_EINVAL;
+  const int32_t total = rtgs_num_tiles(width, height);
+  std::vector<int32_t> tv(tiles, tiles + n_tiles);
+  for (int32_t t : tv)
+    if (t < 0 || t >= total) return RTGS_EINVAL;
+  return launch_order_of(width, height, tv, kind, order);
 }
 
 // workspace: [bbox nn x float4][records nn x 16 float][tails nn x 8 float][distance bounds nn float][slab bounds][group bounds][slab depth keys]
@@ -2191,10 +2311,17 @@ static int trace_impl(const RtgsScene* scene, const RtgsCamera* cam, const RtgsT
     }
     return RTGS_OK;
   }
-  if (params->tile_step <= 0 || params->tile_first < 0 || !(params->t_cutoff >= 0.f)) return RTGS_EINVAL;
+  if (!(params->t_cutoff >= 0.f)) return RTGS_EINVAL;
+  // an explicit tile list is announced by its flag, not by a non-NULL pointer: a rank whose share is EMPTY has no
+  // list to point at, and must render nothing -- not fall back to the arithmetic deal (that was a whole frame written
+  // into a one-tile buffer, found by the two-rank rehearsal in round 4)
+  const bool listed = (params->flags & RTGS_TRACE_TILE_LIST) != 0;
+  if (listed ? (params->tile_count < 0 || (params->tile_count > 0 && !params->tile_list))
+             : (params->tile_list != nullptr || params->tile_step <= 0 || params->tile_first < 0)) return RTGS_EINVAL;
   if ((params->flags & RTGS_TRACE_RESUME) && (!attenuation_buf || !ray_start)) return RTGS_EINVAL;
   if (ray_start && ray_start_stride <= 0) return RTGS_EINVAL;
-  int32_t local = rtgs_num_local_tiles(cam->width, cam->height, params->tile_first, params->tile_step);
+  int32_t local = listed ? params->tile_count
+                         : rtgs_num_local_tiles(cam->width, cam->height, params->tile_first, params->tile_step);
   if (local > tile_limit) local = tile_limit;
   if (local <= 0) return RTGS_OK;  // a shard with no tiles
   if (!projected) {
@@ -2210,6 +2337,8 @@ static int trace_impl(const RtgsScene* scene, const RtgsCamera* cam, const RtgsT
   a.tiles_x = (cam->width + kTile - 1) / kTile;
   a.tile_first = params->tile_first;
   a.tile_step = params->tile_step;
+  a.tile_list = listed ? params->tile_list : nullptr;
+  a.total_tiles = rtgs_num_tiles(cam->width, cam->height);
   a.depth = params->depth;
   a.t_cutoff = params->t_cutoff;
   a.flags = params->flags;
@@ -2316,6 +2445,8 @@ int rtgs_trace_lists(const RtgsScene* scene, const RtgsCamera* cam, const int32_
   p.tile_step = 1;
   p.flags = RTGS_TRACE_SPLIT_OFF;
   p.tile_order = tile_order;
+  p.tile_list = nullptr;
+  p.tile_count = 0;
   return trace_impl(scene, cam, &p, nullptr, nullptr, nullptr, 1, workspace, workspace_bytes, projected, INT32_MAX,
                     stream, lists);
 }
@@ -2373,6 +2504,8 @@ int rtgs_render(const RtgsScene* scene, const RtgsCamera* cam, int32_t depth, fl
   p.tile_step = 1;
   p.flags = 0;
   p.tile_order = nullptr;
+  p.tile_list = nullptr;
+  p.tile_count = 0;
   return trace_impl(scene, cam, &p, sample_out, transmittance_out, nullptr, 1, workspace, workspace_bytes,
                     0, (tile_y1 - tile_y0) * tiles_x, stream);
 }
@@ -2440,6 +2573,45 @@ int rtgs_frames_land(const float* gathered, int32_t world, int32_t tiles_per_ran
                        width, height, (width + kTile - 1) / kTile, images[b]);
   }
   return check_launch();
+}
+
+int rtgs_frames_land_map(const float* const* rank_bufs, const int32_t* rank_tiles, int32_t world, const int32_t* tile_map,
+                         int32_t batch, int32_t n_land, int32_t width, int32_t height, float* const* images,
+                         rtgs_stream_t stream, void* sent_event) {
+  if (world <= 0 || world > kMaxRanks || batch <= 0 || n_land < 0 || n_land > batch || width <= 0 || height <= 0)
+    return RTGS_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // sent_event = "the buffers this step read may be traced into again": the exchange for the senders, and for the
+  // destination -- whose OWN shard is scattered from where it was traced -- the scatter too: recorded last
+  if (n_land == 0) {
+    if (sent_event && hipEventRecord(static_cast<hipEvent_t>(sent_event), s) != hipSuccess) return RTGS_EDEVICE;
+    return RTGS_OK;
+  }
+  if (!rank_bufs || !rank_tiles || !tile_map || !images) return RTGS_EINVAL;
+  int64_t sum = 0;
+  for (int32_t r = 0; r < world; ++r) {
+    if (rank_tiles[r] < 0 || (rank_tiles[r] > 0 && !rank_bufs[r])) return RTGS_EINVAL;
+    sum += rank_tiles[r];
+  }
+  if (sum != rtgs_num_tiles(width, height)) return RTGS_EINVAL;     // a partition: every tile exactly once
+  const int npx = width * height, block = 256;
+  for (int32_t b = 0; b < n_land; ++b) {
+    if (!images[b]) return RTGS_EINVAL;
+    RankBufs bufs;
+    for (int r = 0; r < kMaxRanks; ++r)   // frame b of rank r's batch block: [frame][slot][T][T][3]
+      bufs.p[r] = r < world && rank_bufs[r] ? rank_bufs[r] + (size_t)b * rank_tiles[r] * kTile * kTile * 3 : nullptr;
+    hipLaunchKernelGGL(k_untile_map, dim3((npx + block - 1) / block), dim3(block), 0, s, bufs, tile_map, width, height,
+                       (width + kTile - 1) / kTile, images[b]);
+  }
+  if (sent_event && hipEventRecord(static_cast<hipEvent_t>(sent_event), s) != hipSuccess) return RTGS_EDEVICE;
+  return check_launch();
+}
+
+int rtgs_untile_map(const float* const* rank_bufs, const int32_t* rank_tiles, int32_t world, const int32_t* tile_map,
+                    int32_t width, int32_t height, float* image, rtgs_stream_t stream) {
+  float* const images[1] = {image};
+  if (!image) return RTGS_EINVAL;
+  return rtgs_frames_land_map(rank_bufs, rank_tiles, world, tile_map, 1, 1, width, height, images, stream, nullptr);
 }
 
 #if RTGS_COUNT

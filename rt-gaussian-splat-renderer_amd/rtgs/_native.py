@@ -24,6 +24,7 @@ TRACE_ACCUMULATE = 2
 TRACE_COMPACT = 4
 TRACE_SPLIT_ON = 8     # scheduling only: force / forbid two waves per 8x8 tile
 TRACE_SPLIT_OFF = 16
+TRACE_TILE_LIST = 32   # the shard is RtgsTraceParams.tile_list / tile_count (an empty list renders nothing)
 PEEL_FRESH = 1
 
 LIB_PATH = os.environ.get("RTGS_HIP_LIB") or os.path.join(
@@ -42,7 +43,8 @@ class RtgsCamera(Structure):
 
 class RtgsTraceParams(Structure):
     _fields_ = [("depth", c_int32), ("t_cutoff", c_float), ("tile_first", c_int32),
-                ("tile_step", c_int32), ("flags", c_uint32), ("tile_order", c_void_p)]
+                ("tile_step", c_int32), ("flags", c_uint32), ("tile_order", c_void_p),
+                ("tile_list", c_void_p), ("tile_count", c_int32)]
 
 
 # name -> (restype, argtypes); mirrors include/rtgs_hip.h one to one.
@@ -59,6 +61,7 @@ PROTOTYPES = {
     "rtgs_num_tiles": (c_int32, [c_int32, c_int32]),
     "rtgs_num_local_tiles": (c_int32, [c_int32, c_int32, c_int32, c_int32]),
     "rtgs_launch_order": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "rtgs_launch_order_list": (c_int32, [c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p]),
     "rtgs_trace": (c_int32, [POINTER(RtgsScene), POINTER(RtgsCamera), POINTER(RtgsTraceParams),
                              c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_int32,
                              c_void_p]),
@@ -81,6 +84,9 @@ PROTOTYPES = {
                                    c_int32]),
     "rtgs_frames_land": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                    c_void_p, c_void_p]),
+    "rtgs_frames_land_map": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
+                                       c_void_p, c_void_p]),
+    "rtgs_untile_map": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "rtgs_closest_hit": (c_int32, [POINTER(RtgsScene), c_int32, c_void_p, c_void_p, c_void_p,
                                    c_void_p]),
     "rtgs_accel_bytes": (c_size_t, [c_int32]),

@@ -60,6 +60,158 @@ def cost_sorted_order(width: int, height: int, tile: int, first: int, step: int,
     return out
 
 
+class Partition:
+    """Which rank renders which macro-tiles: ``tiles[r]`` = rank r's tile ids in compact-slot order, together a
+    partition of 0..total-1.  ``round_robin`` is the arithmetic deal (tile t -> rank t mod world: the kernel's
+    (tile_first, tile_step) form, equal shards, one ``dist.gather``); ``weighted`` gives every rank its own share
+    (``RtgsTraceParams.tile_list``, point-to-point exchange of exactly the bytes each shard has).
+
+    Why unequal shares: the destination receives world - 1 shards per frame, each over its own xGMI link, so a
+    frame cannot land faster than ONE shard crosses one link -- 12.4 MB of a 1080p frame at world = 2, as long
+    as a single MI355X needs to render the whole frame.  A destination that keeps the share x of the tiles that
+    balances its own trace against one peer's transfer (``calibrated_shares``) shortens both."""
+
+    PERIOD = 64          # weighted deal: tile t belongs to the owner of residue t mod PERIOD
+    _SPREAD = 37         # residues are dealt out in the order (i * 37) mod 64, so a rank's tiles do not form runs
+
+    def __init__(self, tiles, total: int, name: str):
+        import numpy as np
+        self.tiles = [np.ascontiguousarray(t, dtype=np.int32) for t in tiles]
+        self.world, self.total, self.name = len(self.tiles), int(total), name
+        self.counts = [int(t.size) for t in self.tiles]
+        seen = np.concatenate(self.tiles) if self.tiles else np.zeros(0, np.int32)
+        if seen.size != self.total or not np.array_equal(np.sort(seen), np.arange(self.total, dtype=np.int32)):
+            raise ValueError("not a partition of the frame's tiles")
+        if self.world > 128 or self.total >= 1 << 24:
+            raise ValueError("tile_map packs rank << 24 | slot")
+        self.tile_map = np.empty(self.total, dtype=np.int32)
+        for r, t in enumerate(self.tiles):
+            self.tile_map[t] = (r << 24) | np.arange(t.size, dtype=np.int32)
+        self.arithmetic = name == "round-robin"
+
+    @classmethod
+    def round_robin(cls, total: int, world: int) -> "Partition":
+        import numpy as np
+        return cls([np.arange(r, total, world, dtype=np.int32) for r in range(world)], total, "round-robin")
+
+    @classmethod
+    def weighted(cls, total: int, shares) -> "Partition":
+        """Rank r gets about shares[r] (non-negative, any scale) of the tiles: whole residues mod PERIOD by largest
+        remainder, dealt out in a spread order.  A rank may end up with no tiles at all."""
+        import numpy as np
+        sh = np.asarray(shares, dtype=np.float64)
+        if sh.ndim != 1 or sh.size < 1 or not np.all(np.isfinite(sh)) or np.any(sh < 0) or sh.sum() <= 0:
+            raise ValueError("shares must be non-negative and not all zero")
+        want = sh / sh.sum() * cls.PERIOD
+        m = np.floor(want).astype(np.int64)
+        for r in np.argsort(-(want - m), kind="stable")[:cls.PERIOD - int(m.sum())]:
+            m[r] += 1
+        order = (np.arange(cls.PERIOD) * cls._SPREAD) % cls.PERIOD
+        owner = np.empty(cls.PERIOD, dtype=np.int64)
+        owner[order] = np.repeat(np.arange(sh.size), m)
+        own = owner[np.arange(total) % cls.PERIOD]
+        name = "weighted " + "/".join(str(int(v)) for v in m) + f" of {cls.PERIOD}"
+        return cls([np.nonzero(own == r)[0].astype(np.int32) for r in range(sh.size)], total, name)
+
+    def shares(self):
+        return [c / self.total for c in self.counts]
+
+
+def balanced_share(world: int, t_shard: float, t_frame: float, t_xfer_shard: float) -> float:
+    """The share x of the frame the destination should keep, from three times measured on it (any unit): tracing
+    its 1/world shard, tracing the whole frame, and receiving one exchange of 1/world shards from its peers.
+    Trace time is taken linear in the share, p + c x; an exchange of per-peer share y costs l y (the peers' links
+    run in parallel); the destination's trace and the transfer overlap, so the frame rate is their maximum:
+    p + c x = l (1 - x) / (world - 1).  Clamped to [1 / world, 1]: a link faster than the trace means an equal deal."""
+    n = world
+    if n <= 1:
+        return 1.0
+    c = max((t_frame - t_shard) / (1.0 - 1.0 / n), 0.0)
+    p = max(t_shard - c / n, 0.0)
+    l = max(t_xfer_shard, 0.0) * n
+    lk = l / (n - 1)
+    x = (lk - p) / (c + lk) if (c + lk) > 0 else 1.0 / n
+    return min(max(x, 1.0 / n), 1.0)
+
+
+def _phase(*what):
+    """RTGS_TRACE_PHASES=1: one line on stderr per phase of the multi-rank set-up (a fault or a hang then names its phase)."""
+    if os.environ.get("RTGS_TRACE_PHASES") == "1":
+        import sys
+        print(f"[rtgs rank {os.environ.get('RANK', '?')}]", *what, file=sys.stderr, flush=True)
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
+class _StagedRecv:
+    """A receive into pinned host memory that lands in its device buffer when it is waited for."""
+
+    def __init__(self, work, host, device):
+        self.work, self.host, self.device = work, host, device
+
+    def wait(self):
+        self.work.wait()
+        self.device.copy_(self.host, non_blocking=True)     # (ordered on the current stream, before the scatter)
+        return True
+
+
+def _no_gather(tensor, gather_list=None, dst=0, group=None, async_op=False):
+    """Stand-in for dist.gather while the compute side of the loop is being timed."""
+    return _Done()
+
+
+def calibrated_shares(backend, rank: int, world: int, dst: int = 0, group=None, frames: int = 24) -> dict:
+    """Shares for ``Partition.weighted`` from three times measured here, now, with the real loop (no link rate is
+    assumed): the destination's loop over its 1/world shard with the exchange stubbed out (project + trace with the
+    frames in flight + untile), its loop over whole frames, and one exchange of 1/world shards.  Collective: every
+    rank calls it at the same time; the destination's figures are the ones used and broadcast."""
+    import time
+    sync = getattr(backend, "synchronize", lambda: None)
+
+    def loop(fn, n):
+        fn()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        sync()
+        return (time.perf_counter() - t0) / n
+
+    def frames_of(r, n):
+        def run():
+            for _ in range(4):
+                r.render_frame()
+            r.finish()
+        t = loop(run, max(n // 4, 1)) / 4
+        r.close()
+        return t
+
+    _phase("calibration: shard loop")
+    t_shard = frames_of(TileParallelRenderer(backend=backend, rank=rank, world=world, dst=dst, group=group,
+                                             gather_fn=_no_gather, partition="equal"), frames)
+    _phase("calibration: frame loop")
+    t_frame = frames_of(TileParallelRenderer(backend=backend, rank=0, world=1), max(frames // 2, 4))
+    _phase("calibration: exchange")
+    probe = TileParallelRenderer(backend=backend, rank=rank, world=world, dst=dst, group=group, partition="equal",
+                                 frames_in_flight=1, gather_batch=1)
+    buf, glist = probe.compact[0], (probe._glist[0] if probe._glist else None)
+    dist.barrier(group)
+    t_x = loop(lambda: dist.gather(buf, gather_list=glist, dst=dst, group=group), frames)
+    probe.close()
+    _phase("calibration: broadcast", t_shard, t_frame, t_x)
+    vals = [[t_shard, t_frame, t_x]]
+    dist.broadcast_object_list(vals, src=dst, group=group)
+    t_shard, t_frame, t_x = vals[0]
+    x = balanced_share(world, t_shard, t_frame, t_x)
+    shares = [(1.0 - x) / (world - 1)] * world
+    shares[dst] = x
+    return dict(x=x, shares=shares, equal=bool(x <= 1.02 / world), t_shard_ms=t_shard * 1e3, t_frame_ms=t_frame * 1e3,
+                t_exchange_ms=t_x * 1e3)
+
+
 class HipBackend:
     """The product backend: HIP kernels through the C ABI (include/rtgs_hip.h)."""
 
@@ -115,8 +267,28 @@ class HipBackend:
             self._orders[key] = torch.from_numpy(o).to(self.device)
         return self._orders[key]
 
+    def shard(self, tiles):
+        """Device copies of an explicit tile list and of its launch order: what ``trace(tile_list=...)`` takes."""
+        import numpy as np
+        nat = self.nat
+        tiles = np.ascontiguousarray(tiles, dtype=np.int32)
+        order = None
+        if self.use_tile_order and tiles.size:
+            o = np.empty(tiles.size, dtype=np.int32)
+            got = nat.lib().rtgs_launch_order_list(self.width, self.height, tiles.ctypes.data, tiles.size,
+                                                   0 if self.tile_order_mode == "centre" else 1, o.ctypes.data)
+            nat.check(min(got, 0), "rtgs_launch_order_list")
+            order = torch.from_numpy(o).to(self.device)
+        return dict(list=torch.from_numpy(tiles).to(self.device), count=int(tiles.size), order=order)
+
     def alloc(self, *shape):
         return torch.zeros(shape, dtype=torch.float32, device=self.device)
+
+    def to_device(self, array):
+        return torch.from_numpy(array).to(self.device)
+
+    def synchronize(self):
+        torch.cuda.synchronize(self.device)
 
     def project(self):
         nat = self.nat
@@ -125,7 +297,7 @@ class HipBackend:
                                          nat.stream()), "rtgs_project")
 
     def trace(self, out, tile_first: int, tile_step: int, compact: bool, projected: bool = False,
-              split=None, workspace=None, stream=None):
+              split=None, workspace=None, stream=None, shard=None):
         """split: None = the library picks the kernel form by launch size; True / False force the
         two-waves-per-tile / one-wave-per-tile form (same pixels either way).  stream: a
         torch.cuda.Stream to launch on instead of the current one (the C ABI takes the stream as
@@ -133,12 +305,16 @@ class HipBackend:
         nat = self.nat
         ws = self.workspace if workspace is None else workspace
         st = nat.stream() if stream is None else stream.cuda_stream
-        order = self.tile_order(tile_first, tile_step) if self.use_tile_order else None
         flags = nat.TRACE_COMPACT if compact else 0
         if split is not None:
             flags |= nat.TRACE_SPLIT_ON if split else nat.TRACE_SPLIT_OFF
-        params = nat.RtgsTraceParams(self.depth, self.t_cutoff, tile_first, tile_step, flags,
-                                     nat.ptr(order))
+        if shard is not None:      # an explicit tile list (``shard()``) instead of the (first, step) deal
+            params = nat.RtgsTraceParams(self.depth, self.t_cutoff, 0, 1, flags | nat.TRACE_TILE_LIST, nat.ptr(shard["order"]),
+                                         nat.ptr(shard["list"]) if shard["count"] else None, shard["count"])
+        else:
+            order = self.tile_order(tile_first, tile_step) if self.use_tile_order else None
+            params = nat.RtgsTraceParams(self.depth, self.t_cutoff, tile_first, tile_step, flags,
+                                         nat.ptr(order))
         att = start = None
         if self.depth > nat.MAX_DEPTH:
             # a chain of launches through per-pixel state (rtgs_hip.h, RtgsTraceParams.depth): one
@@ -167,16 +343,16 @@ class HipBackend:
             self._graphs[key] = g
         return g
 
-    def render(self, out, tile_first: int, tile_step: int, compact: bool, stream=None, workspace=None):
+    def render(self, out, tile_first: int, tile_step: int, compact: bool, stream=None, workspace=None, shard=None):
         """project + trace of one shard into `out`: two direct launches on `stream` (default: the
         current stream) with `workspace` (default: the backend's own), or -- opt-in, current stream
         only -- a graph replay / the pipelined form."""
-        if stream is None and self.use_graph:
+        if stream is None and self.use_graph and shard is None:
             self.frame_graph(out, tile_first, tile_step, compact).replay()
-        elif stream is None and self.pipeline:
+        elif stream is None and self.pipeline and shard is None:
             self._render_pipelined(out, tile_first, tile_step, compact)
         else:
-            self.trace(out, tile_first, tile_step, compact, stream=stream, workspace=workspace)
+            self.trace(out, tile_first, tile_step, compact, stream=stream, workspace=workspace, shard=shard)
 
     def _render_pipelined(self, out, tile_first: int, tile_step: int, compact: bool):
         """project on a side stream into workspace f & 1, trace on the caller's stream once that
@@ -215,6 +391,16 @@ class HipBackend:
         st = nat.stream() if stream is None else stream.cuda_stream
         nat.check(nat.lib().rtgs_untile(nat.ptr(gathered), world, tiles_per_rank, self.width,
                                         self.height, nat.ptr(image), st), "rtgs_untile")
+
+    def untile_map(self, bufs, counts, tile_map, image, stream=None):
+        """The landing side of any ``Partition``: bufs[r] = rank r's compact buffer (None for an empty shard)."""
+        import ctypes
+        nat = self.nat
+        st = nat.stream() if stream is None else stream.cuda_stream
+        ptrs = (ctypes.c_void_p * len(bufs))(*[None if b is None else b.data_ptr() for b in bufs])
+        cnt = (ctypes.c_int32 * len(counts))(*counts)
+        nat.check(nat.lib().rtgs_untile_map(ptrs, cnt, len(bufs), nat.ptr(tile_map), self.width, self.height,
+                                            nat.ptr(image), st), "rtgs_untile_map")
 
 
 class _FrameGraph:
@@ -285,15 +471,41 @@ class TileParallelRenderer:
 
     def __init__(self, scene=None, camera=None, depth: int = 16, rank: int = 0, world: int = 1,
                  t_cutoff: float = 0.0, dst: int = 0, group=None, backend=None, gather_fn=None,
-                 frames_in_flight: int | None = None, gather_batch: int | None = None):
+                 frames_in_flight: int | None = None, gather_batch: int | None = None, partition=None, p2p_fn=None):
+        """``partition``: None / "equal" = the round-robin deal (equal shards, one ``dist.gather``); a ``Partition``
+        or a sequence of per-rank shares = that deal (point-to-point exchange of each shard's own bytes); "auto" =
+        ``calibrated_shares`` (every rank must construct its renderer at the same time: it times one shard trace,
+        one frame trace and one exchange on this machine and the destination broadcasts the shares)."""
         self.backend = backend if backend is not None else HipBackend(scene, camera, depth, t_cutoff)
         self._gather = gather_fn if gather_fn is not None else dist.gather   # injectable for tests
+        self._p2p_fn = p2p_fn                                                # likewise: (mine, landing) -> works
         self.rank, self.world, self.dst, self.group = int(rank), int(world), int(dst), group
         b = self.backend
         self.TILE = int(b.tile)
         self.total_tiles = tiles_of(b.width, b.height, self.TILE)
-        self.tiles_per_rank = (self.total_tiles + self.world - 1) // self.world
-        self.local_tiles = local_tile_count(self.total_tiles, self.rank, self.world)
+        self.calibration = None
+        if isinstance(partition, str) and partition == "auto":
+            partition = None
+            if self.world > 1:
+                self.calibration = calibrated_shares(b, self.rank, self.world, self.dst, self.group)
+                if not self.calibration["equal"]:
+                    partition = self.calibration["shares"]
+        if partition is None or (isinstance(partition, str) and partition == "equal"):
+            partition = Partition.round_robin(self.total_tiles, self.world)
+        elif not isinstance(partition, Partition):
+            partition = Partition.weighted(self.total_tiles, partition)
+        if partition.world != self.world or partition.total != self.total_tiles:
+            raise ValueError("partition is of another frame / world size")
+        _phase("deal", partition.name, "local tiles", partition.counts[self.rank])
+        self.partition = partition
+        self.tiles_per_rank = (self.total_tiles + self.world - 1) // self.world     # the arithmetic deal's padded shard
+        self.local_tiles = partition.counts[self.rank]
+        # any other deal: this rank's tile list (device), the frame's tile -> (rank, slot) map (destination)
+        self._shard = self._tile_map = None
+        if not partition.arithmetic:
+            self._shard = b.shard(partition.tiles[self.rank]) if hasattr(b, "shard") else dict(tiles=partition.tiles[self.rank])
+            if self.world == 1 or self.rank == self.dst:
+                self._tile_map = b.to_device(partition.tile_map) if hasattr(b, "to_device") else partition.tile_map
         if frames_in_flight is None:
             frames_in_flight = int(os.environ.get("RTGS_FRAMES_IN_FLIGHT", "2"))
         if gather_batch is None:
@@ -312,7 +524,9 @@ class TileParallelRenderer:
         self._comm = None
         if self.world > 1:
             F, B = self.frames_in_flight, self.gather_batch
-            shard = (self.tiles_per_rank, self.TILE, self.TILE, 3)
+            arith = partition.arithmetic
+            shard = ((self.tiles_per_rank if arith else max(self.local_tiles, 1)), self.TILE, self.TILE, 3)
+            peer = lambda r: (max(partition.counts[r], 1), self.TILE, self.TILE, 3)
             if streams:
                 # batch-slot ring: deep enough that a render stream never waits for the gather of the
                 # batch it traced into last (only for one S batches back, long done)
@@ -320,12 +534,22 @@ class TileParallelRenderer:
                 self.compact = [b.alloc(B, *shard) for _ in range(self._slots)]
                 # gather and landing of consecutive batches are serial on the caller's stream: two
                 # landing buffers are plenty
-                self.gathered = [b.alloc(self.world, B, *shard) for _ in range(2)] if is_dst else []
+                if arith:
+                    self.gathered = [b.alloc(self.world, B, *shard) for _ in range(2)] if is_dst else []
+                else:       # one landing buffer per peer, sized for that peer's share
+                    self.landing = [[None if r == self.rank else b.alloc(B, *peer(r)) for r in range(self.world)]
+                                    for _ in range(2)] if is_dst else []
+                    self.gathered = []
             else:
                 # one-stream form: at most F gathers outstanding, one slot and landing buffer each
                 self._slots = max(F, 2)
                 self.compact = [b.alloc(*shard) for _ in range(self._slots)]
-                self.gathered = [b.alloc(self.world, *shard) for _ in range(self._slots)] if is_dst else []
+                if arith:
+                    self.gathered = [b.alloc(self.world, *shard) for _ in range(self._slots)] if is_dst else []
+                else:
+                    self.landing = [[None if r == self.rank else b.alloc(*peer(r)) for r in range(self.world)]
+                                    for _ in range(self._slots)] if is_dst else []
+                    self.gathered = []
             # the per-rank views torch.distributed.gather wants, made once (8 views cost ~8 us per frame)
             self._glist = [list(g.unbind(0)) for g in self.gathered]
             if streams:
@@ -350,13 +574,20 @@ class TileParallelRenderer:
             nat.check(lib.rtgs_event_create(ctypes.byref(h)), "rtgs_event_create")
             return h.value
 
-        order = b.tile_order(self.rank, self.world) if (b.use_tile_order and self.local_tiles) else None
-        params = nat.RtgsTraceParams(b.depth, b.t_cutoff, self.rank, self.world, nat.TRACE_COMPACT, nat.ptr(order))
+        if self._shard is not None:
+            order = self._shard["order"]
+            params = nat.RtgsTraceParams(b.depth, b.t_cutoff, 0, 1, nat.TRACE_COMPACT | nat.TRACE_TILE_LIST, nat.ptr(order),
+                                         nat.ptr(self._shard["list"]) if self._shard["count"] else None,
+                                         self._shard["count"])
+        else:
+            order = b.tile_order(self.rank, self.world) if (b.use_tile_order and self.local_tiles) else None
+            params = nat.RtgsTraceParams(b.depth, b.t_cutoff, self.rank, self.world, nat.TRACE_COMPACT, nat.ptr(order))
         ws = [b.workspace] + [torch.empty_like(b.workspace) for _ in range(F - 1)]
         state = [(None, None)] * F
         if b.depth > nat.MAX_DEPTH:      # chained launches need per-pixel state, one pair per frame in flight
             state = [(b.alloc(b.width, b.height), b.alloc(b.width, b.height)) for _ in range(F)]
         images = (ctypes.c_void_p * B)(*[fb.data_ptr() for fb in self._fbs]) if self._fbs else None
+        self._counts_c = (ctypes.c_int32 * self.world)(*self.partition.counts)
         return dict(render=[torch.cuda.Stream(device=b.device) for _ in range(F)], ws=ws, state=state,
                     traced=[[event() for _ in range(B)] for _ in range(self._slots)],
                     sent=[event() for _ in range(self._slots)], seen=[None] * F,
@@ -423,12 +654,40 @@ class TileParallelRenderer:
             return
         k = f % self._slots
         if self.local_tiles:
-            b.render(self.compact[k], self.rank, self.world, compact=True)
-        work = self._gather(self.compact[k], gather_list=self._glist[k] if self._glist else None, dst=self.dst,
-                            group=self.group, async_op=True)
+            if self._shard is not None:
+                b.render(self.compact[k], self.rank, self.world, compact=True, shard=self._shard)
+            else:
+                b.render(self.compact[k], self.rank, self.world, compact=True)
+        if self.partition.arithmetic:
+            work = self._gather(self.compact[k], gather_list=self._glist[k] if self._glist else None, dst=self.dst,
+                                group=self.group, async_op=True)
+        else:
+            work = self._p2p(self.compact[k], self.landing[k] if self._fbs else None)
         self._pending.append((work, k))
         while len(self._pending) >= max(self.frames_in_flight, 2):
             self._complete(self._pending.pop(0))
+
+    def _p2p(self, mine, landing):
+        """The exchange step of an unequal deal: every rank sends its shard's own bytes to the destination, which
+        receives each peer's into a buffer of that peer's size (what a gather is made of, without the padding to
+        equal sizes).  Returns the works (complete in the current stream's order once waited for)."""
+        if self._p2p_fn is not None:
+            return self._p2p_fn(mine, landing)
+        peers = [r for r in range(self.world) if r != self.rank and self.partition.counts[r]]
+        if mine.is_cuda and dist.get_backend(self.group) == "gloo":
+            # rehearsal only (gloo's send / recv take host pointers: a device tensor has to be staged by hand --
+            # its gather does that by itself); RCCL moves device memory directly
+            if self.rank == self.dst:
+                host = {r: torch.empty(landing[r].shape, dtype=landing[r].dtype).pin_memory() for r in peers}
+                works = [dist.irecv(host[r], r, group=self.group) for r in peers]
+                return [_StagedRecv(w, host[r], landing[r]) for w, r in zip(works, peers)]
+            return [dist.isend(mine.cpu(), self.dst, group=self.group)] if self.local_tiles else []
+        ops = []
+        if self.rank == self.dst:
+            ops = [dist.P2POp(dist.irecv, landing[r], r, self.group) for r in peers]
+        elif self.local_tiles:
+            ops = [dist.P2POp(dist.isend, mine, self.dst, self.group)]
+        return dist.batch_isend_irecv(ops) if ops else []
 
     def _exchange(self, slot: int, n_frames: int, cur: int) -> None:
         """Gather batch slot `slot` on the caller's stream (it already waits for the batch's traces)
@@ -436,6 +695,22 @@ class TileParallelRenderer:
         cm, b = self._comm, self.backend
         g = cm["g"]
         cm["g"] = g ^ 1
+        if not self.partition.arithmetic:
+            import ctypes
+            for w in self._p2p(self.compact[slot], self.landing[g] if self._fbs else None):
+                w.wait()                      # (NCCL: orders the caller's stream behind the transfer, no host wait)
+            land = n_frames if self._fbs else 0
+            bufs = None
+            if land:
+                bufs = (ctypes.c_void_p * self.world)(*[
+                    (self.compact[slot] if r == self.rank else self.landing[g][r]).data_ptr() if self.partition.counts[r] else None
+                    for r in range(self.world)])
+            b.nat.check(cm["lib"].rtgs_frames_land_map(
+                bufs, self._counts_c, self.world, b.nat.ptr(self._tile_map), self.gather_batch, land, b.width, b.height,
+                cm["images"], cur, cm["sent"][slot]), "rtgs_frames_land_map")
+            if land:
+                self._landed = land - 1
+            return
         self._gather(self.compact[slot], gather_list=self._glist[g] if self._glist else None, dst=self.dst,
                      group=self.group, async_op=False)
         land = n_frames if self._fbs else 0
@@ -447,6 +722,14 @@ class TileParallelRenderer:
 
     def _complete(self, pending) -> None:
         work, k = pending
+        if isinstance(work, list):
+            for w in work:
+                w.wait()
+            if self._fbs:
+                bufs = [(self.compact[k] if r == self.rank else self.landing[k][r]) if self.partition.counts[r] else None
+                        for r in range(self.world)]
+                self.backend.untile_map(bufs, self.partition.counts, self._tile_map, self._fbs[0])
+            return
         work.wait()
         if self._fbs:
             self.backend.untile(self.gathered[k], self.world, self.tiles_per_rank, self._fbs[0])
@@ -478,4 +761,4 @@ class TileParallelRenderer:
         if self.world == 1:
             b.trace(self.framebuffer, 0, 1, compact=False, projected=True)
         elif self.local_tiles:
-            b.trace(self.compact[0], self.rank, self.world, compact=True, projected=True)
+            b.trace(self.compact[0], self.rank, self.world, compact=True, projected=True, shard=self._shard)

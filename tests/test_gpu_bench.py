@@ -37,6 +37,14 @@ def test_bare_bench_with_two_ranks_starts_them_itself_and_verifies(env):
     assert len(pr["trace_ms"]) == 2 and pr["trace_ms_min"] <= pr["trace_ms_max"]
     assert sum(pr["local_tiles"]) == -(-800 // 16) * -(-600 // 16)
     assert "gloo" in line["config"]["parallelism"]            # a rehearsal must say so
+    # both tile deals ran and verified: the equal round-robin one (dist.gather) and the one calibrated on this
+    # machine (unequal shares, explicit tile lists, point to point)
+    parts = line["secondary"]["partitions"]
+    assert set(parts) == {"equal", "auto"} and all(p is not None and p["verified"] is True for p in parts.values())
+    assert parts["equal"]["deal"] == "round-robin" and line["secondary"]["partition_reported"] in parts
+    cal = parts["auto"]["calibration"]
+    assert cal["t_shard_ms"] > 0 and cal["t_frame_ms"] > cal["t_shard_ms"] * 0.5 and cal["t_exchange_ms"] > 0
+    assert abs(sum(parts["auto"]["shares"]) - 1) < 1e-6 and parts["auto"]["shares"][0] >= 0.5 - 1 / 64
 
 
 def test_more_ranks_than_devices_is_refused_with_a_nonzero_status():

@@ -43,7 +43,7 @@ class OracleBackend:
     def project(self):
         pass
 
-    def trace(self, out, tile_first, tile_step, compact, projected=False):
+    def trace(self, out, tile_first, tile_step, compact, projected=False, shard=None):
         self.frame += 1
         img = self.image * float(self.frame)
         if not compact:
@@ -52,13 +52,22 @@ class OracleBackend:
         tx = (W + TILE - 1) // TILE
         total = tx * ((H + TILE - 1) // TILE)
         out.zero_()
-        for local, t in enumerate(range(tile_first, total, tile_step)):
+        tiles = range(tile_first, total, tile_step) if shard is None else shard["tiles"].tolist()
+        for local, t in enumerate(tiles):
             i0, j0 = (t % tx) * TILE, (t // tx) * TILE
             blk = img[i0:i0 + TILE, j0:j0 + TILE]
             out[local, :blk.shape[0], :blk.shape[1]] = blk
 
-    def render(self, out, tile_first, tile_step, compact):
-        self.trace(out, tile_first, tile_step, compact)
+    def render(self, out, tile_first, tile_step, compact, shard=None):
+        self.trace(out, tile_first, tile_step, compact, shard=shard)
+
+    def untile_map(self, bufs, counts, tile_map, image):
+        tx = (W + TILE - 1) // TILE
+        for t in range(tx * ((H + TILE - 1) // TILE)):
+            i0, j0 = (t % tx) * TILE, (t // tx) * TILE
+            w, h = min(TILE, W - i0), min(TILE, H - j0)
+            m = int(tile_map[t])
+            image[i0:i0 + w, j0:j0 + h] = bufs[m >> 24][m & 0xFFFFFF, :w, :h]
 
     def untile(self, gathered, world, tiles_per_rank, image):
         tx = (W + TILE - 1) // TILE
@@ -68,16 +77,25 @@ class OracleBackend:
             image[i0:i0 + w, j0:j0 + h] = gathered[t % world, t // world, :w, :h]
 
 
-def _worker(rank, world, port, frames, q, in_flight=2):
+def _worker(rank, world, port, frames, q, in_flight=2, shares=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         image = _oracle_image()
-        from rtgs.parallel import TileParallelRenderer, local_tile_count, tiles_of
-        r = TileParallelRenderer(backend=OracleBackend(image), rank=rank, world=world, frames_in_flight=in_flight)
+        from rtgs.parallel import Partition, TileParallelRenderer, local_tile_count, tiles_of
+        be = OracleBackend(image)
+        r = TileParallelRenderer(backend=be, rank=rank, world=world, frames_in_flight=in_flight, partition=shares)
+        f0 = be.frame                                # ("auto" has rendered calibration frames, the same number on every rank)
         assert r.frames_in_flight == in_flight and len(r.compact) == max(in_flight, 2)
         assert r.total_tiles == tiles_of(W, H, TILE) == 9
-        assert r.local_tiles == local_tile_count(9, rank, world)
+        if shares is None:
+            assert r.partition.arithmetic and r.local_tiles == local_tile_count(9, rank, world)
+        elif shares == "auto":
+            assert r.calibration is not None and abs(sum(r.calibration["shares"]) - 1) < 1e-9
+            assert sum(r.partition.counts) == 9
+        else:
+            want = Partition.weighted(9, shares)
+            assert not r.partition.arithmetic and r.partition.counts == want.counts and r.local_tiles == want.counts[rank]
         for k in range(frames):
             r.render_frame()
             # at most F frames are outstanding after a call (F - 1 once the oldest has been completed)
@@ -85,7 +103,7 @@ def _worker(rank, world, port, frames, q, in_flight=2):
         r.finish()
         assert not r._pending
         if rank == 0:
-            q.put(float((r.framebuffer - image * float(frames)).abs().max()))
+            q.put(float((r.framebuffer - image * float(f0 + frames)).abs().max()))
     finally:
         dist.destroy_process_group()
 
@@ -155,3 +173,45 @@ def test_launch_orders_are_permutations_and_give_every_xcd_one_wedge():
     # most central first inside a wedge
     m = np.maximum(np.abs((o % tx + 0.5) * T - w / 2) / (w / 2), np.abs((o // tx + 0.5) * T - h / 2) / (h / 2))
     assert np.all(np.diff(m[0:n8:8]) >= 0)
+
+
+@pytest.mark.parametrize("world,frames,in_flight,shares", [(2, 3, 2, (3, 1)), (3, 4, 2, (5, 1, 3)), (3, 2, 3, (5, 0, 1)),
+                                                             (2, 5, 1, (1, 7)), (2, 3, 2, "auto")])
+def test_unequal_shares_reassemble_on_rank0(world, frames, in_flight, shares):
+    # the link-aware deal -- every rank its own share of the tiles (a rank may have none), each shard's
+    # own bytes point to point, the destination's own shard scattered from where it was traced; "auto" runs the
+    # calibration (shard loop, frame loop, one exchange; the destination broadcasts the shares) over gloo
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    mp.spawn(_worker, args=(world, _free_port(), frames, q, in_flight, shares), nprocs=world, join=True)
+    assert q.get(timeout=30) == 0.0
+
+
+def test_partitions_cover_every_tile_once_and_follow_the_shares():
+    import numpy as np
+    from rtgs.parallel import Partition, balanced_share
+    for total in (9, 8160, 32400, 1):
+        for shares in ([1], [1, 1], [0.77, 0.23], [0.3] + [0.1] * 7, [5, 0, 1], [0, 0, 1]):
+            p = Partition.weighted(total, shares)
+            assert sum(p.counts) == total and p.world == len(shares) and not p.arithmetic
+            owner, slot = p.tile_map >> 24, p.tile_map & 0xFFFFFF
+            for r in range(p.world):
+                assert np.array_equal(p.tiles[r], np.nonzero(owner == r)[0])          # slots in increasing tile order
+                assert np.array_equal(slot[p.tiles[r]], np.arange(p.counts[r]))
+            if total >= 8160:
+                got, want = np.array(p.shares()), np.array(shares, float) / sum(shares)
+                assert np.abs(got - want).max() < 1.0 / Partition.PERIOD
+        rr = Partition.round_robin(total, 3)
+        assert rr.arithmetic and [c for c in rr.counts] == [len(range(r, total, 3)) for r in range(3)]
+    with pytest.raises(ValueError):
+        Partition([np.array([0, 1]), np.array([1, 2])], 3, "overlap")
+    with pytest.raises(ValueError):
+        Partition.weighted(9, [0, 0])
+    # the share the destination keeps: link-bound -> most of the frame, link free -> the equal deal
+    assert balanced_share(1, 1.0, 1.0, 1.0) == 1.0
+    assert balanced_share(8, 37e-6, 150e-6, 1e-9) == 1 / 8
+    x2 = balanced_share(2, 80e-6, 150e-6, 200e-6)
+    assert 0.5 < x2 < 1.0
+    # at the balance point the destination's trace time equals one peer's transfer time
+    c = (150e-6 - 80e-6) / 0.5; p0 = 80e-6 - c / 2
+    assert abs((p0 + c * x2) - 200e-6 * 2 * (1 - x2)) < 1e-9
