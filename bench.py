@@ -68,9 +68,9 @@ def parse(argv=None):
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo "
                     "only for functional rehearsal of the N > 1 path)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: all ranks on cuda:0")
-    ap.add_argument("--partition", default="both", choices=["both", "equal", "auto"], help="N > 1: the tile deal -- equal "
-                    "(round-robin, one gather), auto (shares calibrated on this machine, point to point), both = "
-                    "time both and report the faster verified one")
+    ap.add_argument("--partition", default="both", help="N > 1: the tile deal -- equal (round-robin, one gather), auto "
+                    "(shares calibrated on this machine, point to point), both = time both and report the faster "
+                    "verified one; or explicit per-rank shares, e.g. 0.7,0.3")
     ap.add_argument("--dist-timeout", type=float, default=300.0, help="seconds: rendezvous and every collective "
                     "(init_process_group timeout)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds the self-spawned ranks get "
@@ -445,7 +445,16 @@ def rank_main(args) -> int:
 
     # N > 1: the equal round-robin deal (one dist.gather), then the link-aware deal calibrated on this machine
     # (unequal shares, point to point); the line reports the faster of the VERIFIED ones, `secondary.partitions` both
-    modes = ["equal"] if world == 1 else {"both": ["equal", "auto"], "equal": ["equal"], "auto": ["auto"]}[args.partition]
+    if world == 1:
+        modes = ["equal"]
+    elif "," in args.partition:
+        modes = [tuple(float(v) for v in args.partition.split(","))]
+        if len(modes[0]) != world:
+            raise SystemExit(f"--partition names {len(modes[0])} shares for {world} ranks")
+    else:
+        modes = {"both": ["equal", "auto"], "equal": ["equal"], "auto": ["auto"]}.get(args.partition)
+        if modes is None:
+            raise SystemExit("--partition: both | equal | auto | s0,s1,...")
     runs = {}
     for mode in modes:
         try:
@@ -603,11 +612,11 @@ def rank_main(args) -> int:
             line["per_rank"] = per_rank
         if world > 1:
             line["secondary"]["partitions"] = {
-                m: (None if r is None else {"ms_per_step": r["elapsed"] / args.steps * 1e3, "verified": r["verified"],
+                str(m): (None if r is None else {"ms_per_step": r["elapsed"] / args.steps * 1e3, "verified": r["verified"],
                                             "deal": r["partition"], "shares": r["shares"], "calibration": r["calibration"],
                                             "per_rank_trace_ms": r["per_rank"]["trace_ms"]})
                 for m, r in runs.items()}
-            line["secondary"]["partition_reported"] = choice[0]
+            line["secondary"]["partition_reported"] = str(choice[0])
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, arrays, cam, args.cpu_rays)
         print(json.dumps(line), flush=True)

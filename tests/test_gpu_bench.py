@@ -47,6 +47,17 @@ def test_bare_bench_with_two_ranks_starts_them_itself_and_verifies(env):
     assert abs(sum(parts["auto"]["shares"]) - 1) < 1e-6 and parts["auto"]["shares"][0] >= 0.5 - 1 / 64
 
 
+def test_explicit_unequal_shares_cross_the_point_to_point_exchange():
+    # the calibrated deal of a one-GPU gloo rehearsal keeps everything on the destination (the "link" is a host round
+    # trip); explicit shares make rank 1 trace a quarter of the tiles and send exactly those bytes
+    out, line = _run(["--gpus", "2", "--backend", "gloo", "--same-device", "--steps", "4", "--warmup", "1",
+                      "--config", "c2", "--partition", "3,1"])
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert line["verified"] is True and "weighted 48/16 of 64" in line["config"]["parallelism"]
+    tiles = line["per_rank"]["local_tiles"]
+    assert sum(tiles) == 1900 and 0.2 < tiles[1] / 1900 < 0.3
+
+
 def test_more_ranks_than_devices_is_refused_with_a_nonzero_status():
     if torch.cuda.device_count() >= 2:
         pytest.skip("needs a one-GPU box")
