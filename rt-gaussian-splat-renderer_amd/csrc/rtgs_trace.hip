@@ -120,21 +120,6 @@ namespace {
 #define RTGS_TIER 8       // insertions touch only the first RTGS_TIER slots while slot RTGS_TIER-1 is empty in every lane
 #endif                    // (best of 4 / 6 / 8 / 10 / 12; without the tiers c3 0.1634 -> 0.1545 ms)
 
-#ifndef RTGS_SH_STAGE
-#define RTGS_SH_STAGE 0   // 1: SH instantiations stage the coefficients of a list position's distinct Gaussians in LDS once per
-#endif                    // WAVE (LDS-DMA) and read them per lane from there, instead of 64 lanes x 12 gathers.  Same pixels bit
-                          // for bit (GPU suite green with it), but SLOWER as built: c3 + SH 0.291 -> 0.325 ms, c5 1.282 -> 1.713
-                          // (round 4): the gather's bound (vector-L1 tag rate) goes away and a serial chain
-                          // per list position -- exact dedupe loop, DMA latency, four LDS round trips -- takes its place; the
-                          // remedies (staging a wave's ~30 distinct Gaussians once, or two positions in flight) need 6-8 KB of
-                          // LDS per wave, which costs the 1 M-Gaussian form a workgroup per CU
-#ifndef RTGS_STAGE2_ABLATE
-#define RTGS_STAGE2_ABLATE 0   // timing-only forms of RTGS_SH_STAGE=2 (wrong images): 1 no fall-back gathers, 2 nothing fetched either
-#endif
-#ifndef RTGS_SH_FMA
-#define RTGS_SH_FMA 0     // 1: the one-pass gather folds the coefficients in with explicit fmaf chains (sh_add) instead of
-#endif                    // `+=` that the compiler contracts as it likes: c3 + SH 0.291 -> 0.301 ms, c5 1.303 -> 1.542 (141 VGPRs,
-                          // 3 waves per SIMD; 1.323 capped at 128 with 7 spilled); the `+=` form compiles to 127 VGPRs
 #ifndef RTGS_SLAB_ITERS
 #define RTGS_SLAB_ITERS 2
 #endif
@@ -893,7 +878,8 @@ __device__ __forceinline__ unsigned pair_eval(const float4* __restrict__ rec, co
 // `depth` final entries -- a wave ballot skips the rest of the round.  Exact: a terminated ray
 // composites nothing behind those entries, so the image equals the compositing-only cut-off's.
 // colour += sum_q Y_q * sh_q (gaussian.py:165-181) in explicit fma chains: the single-entry paths (listed peel, tie
-// fix-up, single peel).  The one-pass list's gather keeps its `+=` form (RTGS_SH_FMA): within 1 ulp per term of this
+// fix-up).  The list gathers keep a `+=` form the compiler contracts as it likes (within 1 ulp per term of this): with
+// explicit fmaf the 1 M-Gaussian form needs 141 VGPRs instead of 125 (c5 1.303 -> 1.542 ms, c3 + SH 0.291 -> 0.301)
 __device__ __forceinline__ void sh_add(float4& co, const float (&Y)[RTGS_SH_COEFFS], const float* __restrict__ sp) {
 #pragma unroll
   for (int q = 0; q < RTGS_SH_COEFFS; ++q) {
@@ -943,31 +929,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   // surviving slab ids: 16 bits are enough below kBigSceneSlabs (4 096) slabs
   using SlabId = typename std::conditional<kBig, int, unsigned short>::type;
   static_assert(kBig || kBigSceneSlabs <= 65536, "slab ids of small scenes are stored in 16 bits");
-  // SH staging (kStage): kStageSlots x 48 floats per compositing wave, in the LDS that is idle by then -- the slab
-  // list and the group list are dead once a tile's last round of expansion is behind its barrier (the waves
-  // that are still tracing only read the survivor list) -- topped up to 12 KB for the small-scene forms
-  constexpr bool kStage = RTGS_SH_STAGE == 1 && kHasSh && kK == RTGS_MAX_DEPTH;
-  // RTGS_SH_STAGE == 2: ONE staging pass per WORKGROUP -- the 16x16 tile's referenced Gaussians (about 40-60:
-  // neighbouring 8x8 tiles share half of theirs), up to 64 of them, identified by their position in the tile's
-  // survivor list (the list entries carry that position instead of the Gaussian index), deduplicated by a byte
-  // map over the list, fetched once by LDS-DMA, read per lane by all four waves
-  constexpr bool kStage2 = RTGS_SH_STAGE == 2 && kHasSh && kK == RTGS_MAX_DEPTH && kSplit == 1 && !kList;
-  constexpr int kStageSlots = 16, kStageStride = 48;
-  constexpr int kStage2Slots = 64;
-  constexpr unsigned kAbs = 1u << 31;     // kStage2 payloads: id field = Gaussian index (else: survivor-list slot)
-  constexpr int kStageBytes = kWavesPerTile * kStageSlots * kStageStride * (int)sizeof(float);
-  static_assert(kStage2Slots * kStageStride * (int)sizeof(float) == kStageBytes, "both staging forms use the same 12 KB");
-  constexpr int kSlabBytes = (kSlabCap * (int)sizeof(SlabId) + 15) & ~15;
-  constexpr int kSuperInts = (kBig ? TN::kSlabIters * kBlock : 1);
-  constexpr int kMiscBytes = kSlabBytes + kSuperInts * 4 > kStageBytes ? kSlabBytes + kSuperInts * 4 : kStageBytes;
-  __shared__ float4 s_misc[(kStage || kStage2) ? kMiscBytes / 16 + 1 : 1];
-  __shared__ SlabId s_slab_own[(kStage || kStage2) ? 1 : kSlabCap];
-  SlabId* const s_slab = (kStage || kStage2) ? reinterpret_cast<SlabId*>(s_misc) : s_slab_own;
-  // kStage2: which survivor-list slots some ray's list refers to (then: their staging slot, 0xFF = none), the
-  // Gaussian of every staging slot
-  __shared__ unsigned char s_ref[kStage2 ? kListCap : 1];
-  __shared__ int s_stg_g[kStage2 ? kStage2Slots : 1];
-  __shared__ int s_nref[kStage2 ? 1 + kWavesPerTile : 1];
+  __shared__ SlabId s_slab[kSlabCap];
   // depth keys of the first kSortMax listed slabs: only alive between the scan and the sort, when
   // the survivor pool is idle (every batch ends with a barrier) -- they share its LDS
   constexpr int kSortMax = RTGS_SORT_MAX < kListCap ? RTGS_SORT_MAX : kListCap;   // kListCap floats fit the pool
@@ -981,9 +943,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   __shared__ int s_rcnt[kRegions], s_rmore[kRegions];
   constexpr int kSuperStep = kSlabIters * kBlock;   // slab groups scanned per outer step
   constexpr bool kTwo = kBig;   // two-level slab scan (small scenes: c3 0.260 vs 0.261 ms flat, one barrier more)
-  static_assert(kSuperInts == (kTwo ? kSuperStep : 1), "group list size");
-  __shared__ int s_super_own[(kStage || kStage2) ? 1 : kSuperInts];
-  int* const s_super = (kStage || kStage2) ? reinterpret_cast<int*>(reinterpret_cast<char*>(s_misc) + kSlabBytes) : s_super_own;
+  __shared__ int s_super[kTwo ? kSuperStep : 1];
   __shared__ int s_wcnt2[2][kWaves];
 
   const int tid = threadIdx.x;
@@ -1069,10 +1029,6 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz: calibrates the shader clock
   st[0] = __builtin_amdgcn_s_memtime();
 #endif
-  if constexpr (kStage2) {
-#pragma unroll
-    for (int q = 0; q < kListCap / kBlock; ++q) s_ref[q * kBlock + tid] = 0;   // (ordered before any mark by the scan's barriers)
-  }
   int scnt = 0;  // surviving slabs listed so far: identical in every thread
   int turn = 0;  // kSplit == 2: candidates of this 8x8 tile seen so far (wave-uniform)
   // this tile's supertile bin (k_bin), if the frame has bins and the bin did not overflow
@@ -1287,10 +1243,9 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
 #endif
       // ---- every wave: survivors vs its own 8x8 tile, then exact per-ray tests.  The regions
       // are walked as one list; the next chunk's bounds load while this chunk's candidates run.
-      auto fetch = [&](int c, int& g, float4& wb, float& tm, [[maybe_unused]] int& ls) {
+      auto fetch = [&](int c, int& g, float4& wb, float& tm) {
         const int v = c + lane;
         g = -1;
-        ls = 0;
         tm = 0.f;
         wb = make_float4(kInf, kInf, -kInf, -kInf);
         if (v < total) {
@@ -1301,14 +1256,12 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
             if (v >= base) slot = v - base + (r + 1) * kRegionCap;
           }
           g = s_idx[slot];
-          ls = slot;
           wb = bbox[g];
           if constexpr (kHorizon) tm = tmin[g];
         }
       };
       if (wave_live && total > 0) {
         int g, gnext = -1;
-        [[maybe_unused]] int ls, lsnext = 0;
         float4 wb, wbnext = make_float4(kInf, kInf, -kInf, -kInf);
         float tm, tmnext = 0.f;
         // (only rounds of at least kCutMinChunks chunks are worth it: the check costs about as much as
@@ -1320,13 +1273,13 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
           // bits order like the floats)
           unsigned run = kEmpty;
           for (int c = ((total - 1) / kWave) * kWave; c >= 0; c -= kWave) {
-            int gq, lq; float4 wq; float tq;
-            fetch(c, gq, wq, tq, lq);
+            int gq; float4 wq; float tq;
+            fetch(c, gq, wq, tq);
             run = min(run, wave_umin(gq >= 0 ? __float_as_uint(tq) : kEmpty));
             if (lane == 0) s_smin[wave * kChunksMax + c / kWave] = __uint_as_float(run);
           }
         }
-        fetch(0, g, wb, tm, ls);
+        fetch(0, g, wb, tm);
         for (int c = 0; c < total; c += kWave) {
           if (cut_round && c > 0 && (c & kWave) == 0 && total - c > kWave) {   // every other chunk
             // attenuation through the entries nearer than everything still to come, as the
@@ -1342,9 +1295,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
               const bool valid = fin && tb != prev && nh < a.depth;
               prev = tb;
               if (wave_any(valid && !(Tp < a.t_cutoff))) {
-                unsigned gk = kidx[k] >> kSlotBits;
-                if constexpr (kStage2) gk = (kidx[k] & kAbs) ? (gk & 0x3FFFFFFu) : (unsigned)s_idx[gk & 0x3FFFFFFu];
-                const float op = fin ? colop[gk].w : 0.f;
+                const float op = fin ? colop[(kidx[k] >> kSlotBits)].w : 0.f;
                 const float alpha = op * exp_m3(s_wl[(kidx[k] & 15u) * kBlock]);
                 if (valid && !(Tp < a.t_cutoff)) { Tp *= 1.0f - alpha; ++nh; }
               }
@@ -1379,7 +1330,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
             // the next chunk's are issued, so nothing inside the candidate loop waits for memory)
             m &= __ballot(tm < __uint_as_float(min(hz, kEmpty)) || hz >= kEmpty);
           }
-          if (c + kWave < total) fetch(c + kWave, gnext, wbnext, tmnext, lsnext);
+          if (c + kWave < total) fetch(c + kWave, gnext, wbnext, tmnext);
 #if RTGS_ABLATE >= 3
           asm volatile("" ::"s"(m));
           m = 0;
@@ -1482,7 +1433,6 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
               asm volatile("" ::"v"(kn), "v"(wn));
 #else
               unsigned entry = (unsigned)gi;
-              if constexpr (kStage2) entry = (unsigned)__builtin_amdgcn_readlane(ls, b);   // the survivor-list slot, see kStage2
               if constexpr (kSplit == 2) {
                 // arrival rank of this candidate in the tile's stream, above the index bits: the
                 // merge then orders equal t1 exactly as the one-wave form's arrival order does
@@ -1523,7 +1473,6 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
           g = gnext;
           wb = wbnext;
           tm = tmnext;
-          if constexpr (kStage2) ls = lsnext;
         }
       }
       // everyone is done with the list before the next round, the next scan or (two-wave form) the
@@ -1532,14 +1481,6 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
 #if RTGS_STAMPS
       t_mark = __builtin_amdgcn_s_memtime();
 #endif
-      if constexpr (kStage2) {
-        if (more || !last) {   // (rare: a tile whose survivors overflow the list) the slots are about to be reused
-#pragma unroll
-          for (int k = 0; k < kK; ++k)
-            if (!(kidx[k] & kAbs) && key[k] < kEmpty)
-              kidx[k] = kAbs | ((unsigned)s_idx[(kidx[k] >> kSlotBits) & 0x3FFFFFFu] << kSlotBits) | (kidx[k] & kSlotMask);
-        }
-      }
       if (kSplit == 2 || more || !last) __syncthreads();
 #if RTGS_STAMPS
       t_bar += __builtin_amdgcn_s_memtime() - t_mark;
@@ -1729,66 +1670,6 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
     }
   }
 
-  // ---- kStage2: the tile's referenced Gaussians' SH coefficients into LDS, once per workgroup ----
-#if RTGS_COUNT
-  if constexpr (kStage2) { n_exp = 0; n_scan = 0; }
-#endif
-  [[maybe_unused]] unsigned sslots[kStage2 ? kK / 4 : 1];   // staging slot of entry k: byte k % 4 of word k / 4 (0xFF = none)
-  if constexpr (kStage2) {
-    constexpr unsigned kIdMask = 0x3FFFFFFu;
-    // (a) every ray marks the survivor-list slots its entries name
-#pragma unroll
-    for (int k = 0; k < kK; ++k)
-      if (key[k] < kEmpty && !(kidx[k] & kAbs)) s_ref[(kidx[k] >> kSlotBits) & kIdMask] = 1;
-    __syncthreads();
-    // (b) one wave numbers the marked slots (list order: a function of the tile alone) and notes their Gaussians
-    if (wave == 0) {
-      int n = 0;
-      for (int base = 0; base < kListCap; base += kWave) {
-        const bool r = s_ref[base + lane] != 0;
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(r);
-        const int at = n + below(m);
-        s_ref[base + lane] = (r && at < kStage2Slots) ? (unsigned char)at : (unsigned char)0xFF;
-        if (r && at < kStage2Slots) s_stg_g[at] = s_idx[base + lane];
-        n += __popcll(m);
-      }
-      if (lane == 0) s_nref[0] = n < kStage2Slots ? n : kStage2Slots;
-    }
-    __syncthreads();
-    // (c) the four waves fetch them: lane q < 45 brings coefficient q of one Gaussian per instruction, straight into LDS
-    {
-      float* const stage = reinterpret_cast<float*>(s_misc);
-      const int n = __builtin_amdgcn_readfirstlane(s_nref[0]);
-      for (int j = wave; j < n; j += kWaves) {
-        const unsigned gl = (unsigned)__builtin_amdgcn_readfirstlane(s_stg_g[j]);
-#if RTGS_STAGE2_ABLATE >= 2   // timing only: nothing fetched
-        asm volatile("" :: "s"(gl));
-#else
-        if (lane_e < RTGS_SH_COEFFS * 3)
-          __builtin_amdgcn_global_load_lds(
-              (const __attribute__((address_space(1))) void*)(sh + (size_t)gl * (RTGS_SH_COEFFS * 3) + lane_e),
-              (__attribute__((address_space(3))) void*)(stage + j * kStageStride), 4, 0, 0);
-#endif
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    // (d) every entry learns its staging slot and becomes absolute (Gaussian index) for the compositing below
-#pragma unroll
-    for (int w4 = 0; w4 < kK / 4; ++w4) sslots[w4] = 0xFFFFFFFFu;
-#pragma unroll
-    for (int k = 0; k < kK; ++k) {
-      if (key[k] < kEmpty && !(kidx[k] & kAbs)) {
-        const unsigned id = (kidx[k] >> kSlotBits) & kIdMask;
-        const unsigned ss = s_ref[id];
-        sslots[k / 4] = (sslots[k / 4] & ~(0xFFu << (8 * (k % 4)))) | (ss << (8 * (k % 4)));
-        kidx[k] = ((unsigned)s_idx[id] << kSlotBits) | (kidx[k] & kSlotMask);
-      } else {
-        kidx[k] &= ~kAbs;
-      }
-    }
-    __syncthreads();   // every wave's fetches have landed (each waited for its own above)
-  }
-
   float T = 1.f;
 #if !RTGS_STAMPS
   if ((ea->flags & RTGS_TRACE_RESUME) && in_img) T = ea->att[pix];
@@ -1853,114 +1734,23 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
         prev_tbits = tbits;
         float4 co = cog[j];
         if (kHasSh) {
-          bool gather = live;
-          if constexpr (kStage2) gather = live && ((sslots[k / 4] >> (8 * (k % 4))) & 0xFFu) == 0xFFu;
-#if RTGS_STAGE2_ABLATE >= 1   // timing only: no fall-back gathers
-          if constexpr (kStage2) gather = false;
-#endif
-          if (gather) {   // (gathering for every slot, valid or not, to batch the loads: 2.24 vs 2.08 ms on c5)
-            // (records padded to 192 or 256 B and 16-B aligned: c3 + SH 0.310 -> 0.333 / 0.381 ms --
-            // the gather is bound by the lines it touches.  SH per (wave, insertion event) through
-            // scalar loads instead -- a wave logs ~23 events while its lanes composite ~14 entries
-            // each -- with the weights T alpha handed over in the exponent slots: c3 + SH 0.289 ->
-            // 0.317, c5 1.30 -> 1.99: one event's 45 coefficients at a time leaves the scalar-load
-            // latency exposed, the log's LDS costs c5 a workgroup per CU, and 23 x 68 v_pk_fma_f32
-            // per wave is 1.6 x the arithmetic of 14 x 68.  Coefficients read per lane from LDS
-            // instead (timing-only build of round 2, nothing staged): c3 + SH 0.290 -> 0.200,
-            // c5 1.306 -> 1.122 -- the bound of staging a wave's distinct Gaussians in LDS; but the
-            // 192 B per staged Gaussian cost a workgroup per CU beyond ~20 per wave, and with one
-            // workgroup less the same builds run at 0.281 / 1.385: nothing left.)
-            if constexpr (!kStage) {
-#if RTGS_SH_FMA
-            sh_add(co, Ysh, sh + (size_t)gi * (RTGS_SH_COEFFS * 3));
-#else
+          if (live) {   // (gathering for every slot, valid or not, to batch the loads: 2.24 vs 2.08 ms on c5)
+            // (records padded to 192 or 256 B and 16-B aligned: c3 + SH 0.310 -> 0.333 / 0.381 ms.  SH per (wave,
+            // insertion event) through scalar loads: 0.289 -> 0.317, c5 1.30 -> 1.99.  Round 4, the coefficients
+            // STAGED IN LDS and read per lane from there, two builds, both bit-identical in their pixels and both
+            // dropped (commits b90b368 and 3c75e8a): per wave and list position (exact dedupe
+            // loop + LDS-DMA, 16 slots in the LDS that is idle by then): c3 + SH 0.291 -> 0.325, c5 1.282 -> 1.713;
+            // per workgroup, once (survivor-list slots as identity, byte-map dedupe, 64 slots, three barriers):
+            // 97.5 % of c3 + SH's entries shaded from LDS and k_trace 0.290 -> 0.288, c5 1.293 -> 1.448 -- and with
+            // NOTHING fetched at all 0.2685 / 1.290.  The gather is not what this phase waits for: a workgroup of
+            // the SH form lives 74 k cycles against 65 k without SH, but only 4 of them fit a CU (125 VGPRs)
+            // instead of 7 (profiles/r04_phase_stamps.txt).)
             const float* sp = sh + (size_t)gi * (RTGS_SH_COEFFS * 3);
 #pragma unroll
             for (int q = 0; q < RTGS_SH_COEFFS; ++q) {
               co.x += Ysh[q] * sp[3 * q + 0];
               co.y += Ysh[q] * sp[3 * q + 1];
               co.z += Ysh[q] * sp[3 * q + 2];
-            }
-#endif
-            }
-          }
-          if constexpr (kStage2) {
-            // the coefficients from the workgroup's staging (see above) for the entries that have a slot; the
-            // few that have none (more than 64 referenced Gaussians in the tile, or a tile whose survivor list was
-            // refilled) gather from memory as the plain form does.  Same values, same order of operations.
-            const unsigned ss = (sslots[k / 4] >> (8 * (k % 4))) & 0xFFu;
-#if RTGS_COUNT   // (counting build with RTGS_SH_STAGE=2: slots 5 / 6 count the entries shaded from the staging / from memory)
-            n_exp += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(live && ss != 0xFFu));
-            n_scan += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(live && ss == 0xFFu));
-#endif
-            if (live && ss != 0xFFu) {
-              const float4* lp = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(s_misc) + ss * kStageStride);
-#pragma unroll
-              for (int c4 = 0; c4 < 4; ++c4) {
-                const float4 v0 = lp[3 * c4], v1 = lp[3 * c4 + 1], v2 = lp[3 * c4 + 2];
-                const float cf[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                  if (4 * c4 + q < RTGS_SH_COEFFS) {
-                    co.x += Ysh[4 * c4 + q] * cf[3 * q + 0];
-                    co.y += Ysh[4 * c4 + q] * cf[3 * q + 1];
-                    co.z += Ysh[4 * c4 + q] * cf[3 * q + 2];
-                  }
-                }
-              }
-            }
-          }
-          if constexpr (kStage) {
-            // Round 4: the gather above is bound by the vector L1's tag rate -- 64 lanes x 12 loads per entry, ~25
-            // line accesses per load (the TCP coalesces inside quarter-waves only): TCP_TOTAL_CACHE_ACCESSES at
-            // 0.94 of one per clock per CU on c3 + SH (profiles/r04_c3sh_summary.json) -- for ~12 distinct
-            // Gaussians among the 64 lanes of a list position.  So the WAVE fetches each distinct Gaussian's 45
-            // coefficients once, straight into LDS (global_load_lds: lane q < 45 brings coefficient q, 3 lines,
-            // no VGPRs), and every lane reads its own Gaussian's from there; same values, same order of
-            // operations: pixels unchanged bit for bit.  Exact dedupe: the first pending lane's Gaussian is
-            // broadcast, the lanes that hold it take the slot, repeat (a position with more than kStageSlots
-            // distinct Gaussians takes another pass).
-            float* const stg = reinterpret_cast<float*>(s_misc) + sub * (kStageSlots * kStageStride);
-            bool want = live;
-            unsigned long long pend = __builtin_amdgcn_ballot_w64(want);
-            while (pend) {
-              // (the previous position's reads of the slots are complete before they are written again)
-              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-              unsigned long long todo = pend;
-              int nslot = 0, slot_l = -1;
-              while (todo && nslot < kStageSlots) {
-                const unsigned gl = (unsigned)__builtin_amdgcn_readlane((int)gi, __builtin_ctzll(todo));
-                const bool mine = want && gi == gl;
-                slot_l = mine ? nslot : slot_l;
-                if (lane_e < RTGS_SH_COEFFS * 3)
-                  __builtin_amdgcn_global_load_lds(
-                      (const __attribute__((address_space(1))) void*)(sh + (size_t)gl * (RTGS_SH_COEFFS * 3) + lane_e),
-                      (__attribute__((address_space(3))) void*)(stg + nslot * kStageStride), 4, 0, 0);
-                todo &= ~__builtin_amdgcn_ballot_w64(mine);
-                ++nslot;
-              }
-              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-              if (slot_l >= 0) {
-                // four steps of 12 floats (4 coefficients x rgb): all 48 in flight at once cost the c5 instantiation
-                // 34 VGPRs and a wave per SIMD
-                const float4* lp = reinterpret_cast<const float4*>(stg + slot_l * kStageStride);
-#pragma unroll
-                for (int c4 = 0; c4 < 4; ++c4) {
-                  const float4 v0 = lp[3 * c4], v1 = lp[3 * c4 + 1], v2 = lp[3 * c4 + 2];
-                  const float cf[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
-#pragma unroll
-                  for (int q = 0; q < 4; ++q) {
-                    if (4 * c4 + q < RTGS_SH_COEFFS) {
-                      co.x = fmaf(Ysh[4 * c4 + q], cf[3 * q + 0], co.x);
-                      co.y = fmaf(Ysh[4 * c4 + q], cf[3 * q + 1], co.y);
-                      co.z = fmaf(Ysh[4 * c4 + q], cf[3 * q + 2], co.z);
-                    }
-                  }
-                  asm volatile("" ::: "memory");   // (keeps the next step's reads behind this step's arithmetic)
-                }
-                want = false;
-              }
-              pend = __builtin_amdgcn_ballot_w64(want);
             }
           }
         }
