@@ -259,6 +259,15 @@ int rtgs_shard_frame(const RtgsScene* scene, const RtgsCamera* cam, const RtgsTr
                      rtgs_stream_t render_stream, void* reuse_event, void* traced_event,
                      rtgs_stream_t consumer_stream, int32_t consumer_waits);
 
+/* One frame whose projection runs on a stream of its own (ABI v6): [project_stream waits for reuse_event, the last
+ * trace that read `workspace`, unless complete or NULL] -> rtgs_project_shard there -> projected_event ->
+ * [trace_stream waits for it] -> rtgs_trace(projected = 1) there -> traced_event (may be NULL).  With two
+ * workspaces in alternation frame f+1's k_project / k_bin run while frame f's k_trace still fills the chip. */
+int rtgs_frame_ahead(const RtgsScene* scene, const RtgsCamera* cam, const RtgsTraceParams* params, float* out,
+                     float* attenuation_buf, float* ray_start, void* workspace, size_t workspace_bytes,
+                     rtgs_stream_t project_stream, rtgs_stream_t trace_stream, void* reuse_event, void* projected_event,
+                     void* traced_event);
+
 /* Destination side, after the gather was queued on `stream`: records sent_event there (the senders'
  * buffers may be reused once it completes; may be NULL), then scatters the first n_land of `batch`
  * frames -- gathered[rank][frame][local_tile][T][T][3], every rank's block holding `batch` frames'

@@ -2471,6 +2471,34 @@ int rtgs_shard_frame(const RtgsScene* scene, const RtgsCamera* cam, const RtgsTr
   return RTGS_OK;
 }
 
+// One frame with its projection on a stream of its own: [project_stream waits for reuse_event -- the last trace that
+// read this workspace -- unless it is complete or NULL] -> rtgs_project_shard on project_stream -> projected_event ->
+// [trace_stream waits for it] -> rtgs_trace(projected) on trace_stream -> traced_event (may be NULL).  A caller that
+// alternates two workspaces gets frame f+1's k_project / k_bin (latency-bound, a few CUs) executed while frame f's
+// k_trace still fills the chip.
+int rtgs_frame_ahead(const RtgsScene* scene, const RtgsCamera* cam, const RtgsTraceParams* params, float* out,
+                     float* attenuation_buf, float* ray_start, void* workspace, size_t workspace_bytes,
+                     rtgs_stream_t project_stream, rtgs_stream_t trace_stream, void* reuse_event, void* projected_event,
+                     void* traced_event) {
+  if (!params || !cam || !projected_event) return RTGS_EINVAL;
+  hipStream_t ps = static_cast<hipStream_t>(project_stream), ts = static_cast<hipStream_t>(trace_stream);
+  if (reuse_event && hipEventQuery(static_cast<hipEvent_t>(reuse_event)) != hipSuccess) {
+    (void)hipGetLastError();
+    if (hipStreamWaitEvent(ps, static_cast<hipEvent_t>(reuse_event), 0) != hipSuccess) return RTGS_EDEVICE;
+  }
+  const bool listed = (params->flags & RTGS_TRACE_TILE_LIST) != 0;
+  const int32_t local = listed ? params->tile_count
+                               : rtgs_num_local_tiles(cam->width, cam->height, params->tile_first, params->tile_step);
+  if (int rc = project_impl(scene, cam, workspace, workspace_bytes, project_stream, shard_wants_bins(cam, local))) return rc;
+  if (hipEventRecord(static_cast<hipEvent_t>(projected_event), ps) != hipSuccess) return RTGS_EDEVICE;
+  if (hipStreamWaitEvent(ts, static_cast<hipEvent_t>(projected_event), 0) != hipSuccess) return RTGS_EDEVICE;
+  if (int rc = trace_impl(scene, cam, params, out, attenuation_buf, ray_start, 1, workspace, workspace_bytes, 1, INT32_MAX,
+                          trace_stream))
+    return rc;
+  if (traced_event && hipEventRecord(static_cast<hipEvent_t>(traced_event), ts) != hipSuccess) return RTGS_EDEVICE;
+  return RTGS_OK;
+}
+
 int rtgs_frames_land(const float* gathered, int32_t world, int32_t tiles_per_rank, int32_t batch, int32_t n_land,
                      int32_t width, int32_t height, float* const* images, rtgs_stream_t stream, void* sent_event) {
   if (world <= 0 || tiles_per_rank <= 0 || batch <= 0 || n_land < 0 || n_land > batch || width <= 0 || height <= 0)

@@ -82,6 +82,8 @@ PROTOTYPES = {
     "rtgs_shard_frame": (c_int32, [POINTER(RtgsScene), POINTER(RtgsCamera), POINTER(RtgsTraceParams), c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_int32]),
+    "rtgs_frame_ahead": (c_int32, [POINTER(RtgsScene), POINTER(RtgsCamera), POINTER(RtgsTraceParams), c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rtgs_frames_land": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                    c_void_p, c_void_p]),
     "rtgs_frames_land_map": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,

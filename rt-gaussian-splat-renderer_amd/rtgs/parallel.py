@@ -355,36 +355,40 @@ class HipBackend:
             self.trace(out, tile_first, tile_step, compact, stream=stream, workspace=workspace, shard=shard)
 
     def _render_pipelined(self, out, tile_first: int, tile_step: int, compact: bool):
-        """project on a side stream into workspace f & 1, trace on the caller's stream once that
-        projection is done.  A frame's own latency is what it was (its trace waits for its
-        projection); a host that queues frames ahead of the GPU -- a turntable, bench.py, the
-        tile-parallel loop -- gets frame f+1's k_project / k_bin executed in the shadow of frame f's
-        k_trace, whose last workgroups leave most of the chip idle.  The pose and the scene pointers
-        are read when the frame is queued, as without the pipeline."""
+        """project on a side stream into workspace f & 1, trace on the caller's stream once that projection is
+        done: ONE library call (``rtgs_frame_ahead``: two stream waits, two event records, the launches).  A
+        frame's own latency is what it was (its trace waits for its projection); a host that queues frames ahead
+        of the GPU -- a turntable, bench.py -- gets frame f+1's k_project / k_bin (latency-bound, a few CUs)
+        executed while frame f's k_trace fills the chip.  The pose and the scene pointers are read when the frame
+        is queued, as without the pipeline."""
+        import ctypes
         nat = self.nat
+        lib = nat.lib()
         if self._pipe is None:
+            def event():
+                h = ctypes.c_void_p()
+                nat.check(lib.rtgs_event_create(ctypes.byref(h)), "rtgs_event_create")
+                return h.value
             self._pipe = dict(stream=torch.cuda.Stream(device=self.device), turn=0,
                               ws=[self.workspace, torch.empty_like(self.workspace)],
-                              projected=[torch.cuda.Event(), torch.cuda.Event()],
-                              traced=[torch.cuda.Event(), torch.cuda.Event()])
+                              projected=[event(), event()], traced=[event(), event()], params={})
         pp = self._pipe
         k = pp["turn"] & 1
         pp["turn"] += 1
-        main = torch.cuda.current_stream(self.device)
         side = pp["stream"]
+        key = self.scene.content_key()
+        if pp.get("scene_key") != key:
+            side.wait_stream(nat.current_stream(self.device.index))   # scene uploads / edits queued on the caller's stream
+            pp["scene_key"] = key
+        pk = (tile_first, tile_step, compact)
+        if pk not in pp["params"]:
+            order = self.tile_order(tile_first, tile_step) if self.use_tile_order else None
+            pp["params"][pk] = (nat.RtgsTraceParams(self.depth, self.t_cutoff, tile_first, tile_step,
+                                                    nat.TRACE_COMPACT if compact else 0, nat.ptr(order)), order)
         ws = pp["ws"][k]
-        side.wait_event(pp["traced"][k])       # the trace two frames back was the last reader of ws
-        if pp.get("scene_version") != self.scene.version:
-            side.wait_stream(main)             # scene uploads / edits queued on the caller's stream
-            pp["scene_version"] = self.scene.version
-        with torch.cuda.stream(side):
-            nat.check(nat.lib().rtgs_project_shard(self.scene.native(), self.camera.native(), tile_first,
-                                                   tile_step, nat.ptr(ws), ws.numel(), nat.stream()),
-                      "rtgs_project_shard")
-            pp["projected"][k].record(side)
-        main.wait_event(pp["projected"][k])
-        self.trace(out, tile_first, tile_step, compact, projected=True, workspace=ws)
-        pp["traced"][k].record(main)
+        nat.check(lib.rtgs_frame_ahead(self.scene_native(), self.camera_native(), pp["params"][pk][0], nat.ptr(out), None, None,
+                                       nat.ptr(ws), ws.numel(), side.cuda_stream, nat.stream(), pp["traced"][k],
+                                       pp["projected"][k], pp["traced"][k]), "rtgs_frame_ahead")
 
     def untile(self, gathered, world: int, tiles_per_rank: int, image, stream=None):
         nat = self.nat
