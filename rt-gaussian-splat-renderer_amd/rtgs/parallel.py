@@ -10,6 +10,11 @@ W*H*12/world bytes per rank -- lands the shards on the destination rank, where `
 de-interleaves them into the (W, H, 3) framebuffer.  Every rank keeps F frames in flight
 (``TileParallelRenderer``, default 2): frame f is traced on render stream f mod F while the gather of
 the frames before it runs on the caller's stream.
+
+Round 4: the deal need not be equal.  ``Partition`` names every rank's tiles explicitly (``RtgsTraceParams.tile_list``),
+``Partition.weighted`` gives every rank its own share, the exchange is then point to point (each shard's own bytes) and
+the destination scatters through a tile -> (rank, slot) map (``rtgs_frames_land_map``); ``partition="auto"`` measures,
+on the machine it runs on, the share the destination should keep (``calibrated_shares``).
 """
 
 from __future__ import annotations
@@ -239,8 +244,9 @@ class HipBackend:
         self._graphs = {}
         # Optional (RTGS_PIPELINE=1): frame f+1's projection on a second stream, into a second
         # workspace, while frame f is still being traced.  OFF by default: measured on MI355X / ROCm
-        # 7.2 the two cross-stream event waits per frame cost more than the overlap returns (c3
-        # 0.1553 -> 0.1618 ms per frame, c5 1.345 -> 1.382 with the host queueing 200 frames ahead)
+        # 7.2 the two cross-stream event waits per frame cost more than the overlap returns -- also as ONE
+        # library call with raw events (rtgs_frame_ahead, round 4): c3 0.1502 -> 0.1547 ms per frame,
+        # c5 1.320 -> 1.344, c2 0.0485 -> 0.0541 with the host queueing 200 frames ahead
         self.pipeline = os.environ.get("RTGS_PIPELINE", "0") == "1"
         self._pipe = None
 
