@@ -146,6 +146,23 @@ def _phase(*what):
         print(f"[rtgs rank {os.environ.get('RANK', '?')}]", *what, file=sys.stderr, flush=True)
 
 
+def _side_stream(device, priority: str = "low"):
+    """A stream for work that should fill the chip only where the caller's stream leaves it idle (the next frame's
+    projection behind this frame's trace): the LOWEST priority the device offers (torch.cuda.Stream only reaches the
+    normal and the high level), wrapped for torch.  priority="normal": a plain torch stream."""
+    if priority != "low":
+        return torch.cuda.Stream(device=device)
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    least, greatest = ctypes.c_int(0), ctypes.c_int(0)
+    if hip.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest)) != 0:
+        return torch.cuda.Stream(device=device)
+    handle = ctypes.c_void_p()
+    if hip.hipStreamCreateWithPriority(ctypes.byref(handle), 1, least.value) != 0:      # 1 = hipStreamNonBlocking
+        return torch.cuda.Stream(device=device)
+    return torch.cuda.ExternalStream(handle.value, device=device)
+
+
 class _Done:
     def wait(self):
         return True
@@ -375,7 +392,7 @@ class HipBackend:
                 h = ctypes.c_void_p()
                 nat.check(lib.rtgs_event_create(ctypes.byref(h)), "rtgs_event_create")
                 return h.value
-            self._pipe = dict(stream=torch.cuda.Stream(device=self.device), turn=0,
+            self._pipe = dict(stream=_side_stream(self.device, os.environ.get("RTGS_PIPELINE_PRIO", "low")), turn=0,
                               ws=[self.workspace, torch.empty_like(self.workspace)],
                               projected=[event(), event()], traced=[event(), event()], params={})
         pp = self._pipe
