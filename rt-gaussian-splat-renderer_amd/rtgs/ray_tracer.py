@@ -40,7 +40,8 @@ class RayTracer:
         self._orders = {}            # (tile_first, tile_step) -> device int32 launch order
         # RTGS_TILE_ORDER as in parallel.HipBackend: 0 = tile order, centre, wedge (default)
         self._order_mode = os.environ.get("RTGS_TILE_ORDER", "wedge")
-        self._att_cleared = False    # clear_attenuation() ran while sample_all's per-pixel state was still owed
+        self._replay_owed = False    # the ray field's pending update is sample_all's replay (it owes the attenuation too)
+        self._att_cleared = False    # clear_attenuation() ran while that replay was still owed
         # peel lists (rtgs_trace_lists / rtgs_peel): the sample() pattern from one traversal.  RTGS_PEEL_LISTS=0:
         # every sample() re-traverses (the K = 1 resumed launch), as up to round 3
         self._use_lists = os.environ.get("RTGS_PEEL_LISTS", "1") != "0"
@@ -131,10 +132,12 @@ class RayTracer:
         beats handing out the state of a frame that was never rendered.  `rays_superseded`: the rays
         are being regenerated anyway (``Camera.generate_ray_field``), only the attenuation is still owed
         -- and not even that once ``clear_attenuation()`` has run."""
+        self._replay_owed = False
         if rays_superseded and self._att_cleared:
             self._att_cleared = False
             return
         if key != self._state_key():
+            self._replay_owed = True          # (the debt stands: RayField.materialise keeps the update pending)
             raise RuntimeError(
                 "the scene (or focal length) changed after sample_all(): the per-pixel state of that sample "
                 "(attenuation_buf, cam_ray_field.start) can no longer be reconstructed.  Read it before "
@@ -213,6 +216,7 @@ class RayTracer:
                                           self._lists.numel(), k, nat.PEEL_FRESH if first else 0,
                                           nat.ptr(self.sample_buf), nat.ptr(self._attenuation), nat.stream()), "rtgs_peel")
             self._list_peels = self._state_peels = k + 1
+            self._replay_owed = False
             # .start (and the rays) are owed again: what a reader sees is the state after k + 1 peels
             self.camera.defer_ray_field(pos, rot, lambda: self._start_from_lists(pos, rot), True)
         else:
@@ -265,10 +269,12 @@ class RayTracer:
             raise RuntimeError("sample_all() needs num_steps == 0 (finish the partial sample first)")
         depth = int(depth)
         pos, rot = self._pose()
-        self._att_cleared = False
+        self._att_cleared = self._replay_owed = False
+        self._list_peels = None              # the per-pixel state is this sample's from here on, not the lists'
         if depth <= nat.MAX_DEPTH and lazy_state:
             self.trace(depth, flags=nat.TRACE_ACCUMULATE, t_cutoff=t_cutoff, state=False)
             key = self._state_key()
+            self._replay_owed = True
             self.camera.defer_ray_field(pos, rot, lambda: self._replay_state(pos, rot, depth, t_cutoff, key), True,
                                         lambda: self._replay_state(pos, rot, depth, t_cutoff, key, True))
         else:
@@ -284,8 +290,7 @@ class RayTracer:
     def clear_attenuation(self):
         """ray_tracer.py:62-66.  While ``sample_all``'s per-pixel state is still owed, the attenuation
         part of that debt is cancelled: the replay ends by filling ones again."""
-        f = self.camera.cam_ray_field
-        if f.pending and f.state_deferred:
+        if self.camera.cam_ray_field.pending and self._replay_owed:
             self._att_cleared = True
         nat.check(nat.lib().rtgs_fill(nat.ptr(self._attenuation), self._attenuation.numel(),
                                       1.0, nat.stream()), "rtgs_fill")
