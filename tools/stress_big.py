@@ -18,7 +18,17 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record()
 for _ in range(5): tr.trace(16)
 e1.record(); torch.cuda.synchronize()
-print(f"{e0.elapsed_time(e1)/5:.3f} ms/frame", flush=True)
+print(f"{e0.elapsed_time(e1)/5:.3f} ms/frame (k_trace alone: RayTracer.trace reuses the projection of an unchanged pose)", flush=True)
+from rtgs.parallel import TileParallelRenderer
+r = TileParallelRenderer(scene, camera, depth=16)
+for _ in range(2): r.render_frame()
+torch.cuda.synchronize(); e0.record()
+for _ in range(5): r.render_frame()
+e1.record(); torch.cuda.synchronize()
+print(f"{e0.elapsed_time(e1)/5:.3f} ms/frame with the per-frame projection and bins", flush=True)
+del r
+if os.environ.get("RTGS_STRESS_TIME_ONLY") == "1":
+    sys.exit(0)
 rng = np.random.default_rng(3)
 npx = max(64, min(1200, int(3.6e9 // n)))
 pix = np.stack([rng.integers(0, w, npx), rng.integers(0, h, npx)], -1).astype(np.int32)
