@@ -58,6 +58,24 @@ def test_explicit_unequal_shares_cross_the_point_to_point_exchange():
     assert sum(tiles) == 1900 and 0.2 < tiles[1] / 1900 < 0.3
 
 
+def test_launched_by_torch_distributed_run_it_is_a_rank_as_before():
+    # the driver's other launch form: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--backend", "gloo", "--same-device", "--steps", "4", "--warmup", "1",
+                          "--config", "c2", "--partition", "equal"], capture_output=True, text=True, timeout=900, env=e, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                     # ONE line, from rank 0
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["verified"] is True and set(line["secondary"]["partitions"]) == {"equal"}
+
+
 def test_more_ranks_than_devices_is_refused_with_a_nonzero_status():
     if torch.cuda.device_count() >= 2:
         pytest.skip("needs a one-GPU box")
