@@ -70,7 +70,8 @@ def parse(argv=None):
     ap.add_argument("--same-device", action="store_true", help="rehearsal: all ranks on cuda:0")
     ap.add_argument("--partition", default="both", help="N > 1: the tile deal -- equal (round-robin, one gather), auto "
                     "(shares calibrated on this machine, point to point), both = time both and report the faster "
-                    "verified one; or explicit per-rank shares, e.g. 0.7,0.3")
+                    "verified one; wedges = one compact image sector per rank, its projection culled to it (all = "
+                    "the three of them); or explicit per-rank shares, e.g. 0.7,0.3")
     ap.add_argument("--dist-timeout", type=float, default=300.0, help="seconds: rendezvous and every collective "
                     "(init_process_group timeout)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds the self-spawned ranks get "
@@ -452,9 +453,10 @@ def rank_main(args) -> int:
         if len(modes[0]) != world:
             raise SystemExit(f"--partition names {len(modes[0])} shares for {world} ranks")
     else:
-        modes = {"both": ["equal", "auto"], "equal": ["equal"], "auto": ["auto"]}.get(args.partition)
+        modes = {"both": ["equal", "auto"], "all": ["equal", "auto", "wedges"], "equal": ["equal"], "auto": ["auto"],
+                 "wedges": ["wedges"]}.get(args.partition)
         if modes is None:
-            raise SystemExit("--partition: both | equal | auto | s0,s1,...")
+            raise SystemExit("--partition: both | all | equal | auto | wedges | s0,s1,...")
     runs = {}
     for mode in modes:
         try:

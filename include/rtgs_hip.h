@@ -92,6 +92,8 @@ typedef struct RtgsCamera {
 #define RTGS_TRACE_SPLIT_OFF 16u
 #define RTGS_TRACE_TILE_LIST 32u  /* the shard is tile_list[0 .. tile_count) (ABI v6), not (tile_first, tile_step);
                                      tile_count = 0 (an empty share) renders nothing */
+#define RTGS_TRACE_REGION 64u     /* the shard's tiles all lie inside RtgsTraceParams.region: the projection this call
+                                     runs skips the Gaussians that cannot reach it (same pixels) */
 
 typedef struct RtgsTraceParams {
   int32_t depth;        /* peels performed by this call, >= 1.  Above RTGS_MAX_DEPTH the call  */
@@ -112,6 +114,12 @@ typedef struct RtgsTraceParams {
                            (rtgs.parallel.Partition) -- and local tile l (compact slot l, tile_order's index) is
                            tile_list[l]; tile_first / tile_step are ignored.  Must be NULL without the flag. */
   int32_t tile_count;
+  float region[4];      /* with RTGS_TRACE_REGION (ABI v6): a rectangle of pixel-centre offsets from the image centre,
+                           (X lo, Y lo, X hi, Y hi) with X = i + 0.5 - W/2, Y = j + 0.5 - H/2, that contains every pixel
+                           of the shard -- one compact part of the frame per rank (rtgs.parallel.Partition.wedges).
+                           The per-frame projection of this call (projected = 0, rtgs_shard_frame, rtgs_frame_ahead)
+                           then treats Gaussians whose conservative screen bound misses it as culled: at 1 M
+                           Gaussians an eighth-of-the-frame sector skips most of k_project's arithmetic and writes. */
 } RtgsTraceParams;
 
 int rtgs_abi_version(void);

@@ -267,7 +267,8 @@ __global__ __launch_bounds__(kThreads) void k_project(int32_t n, const float* __
                                                   float4* __restrict__ super_bbox,
                                                   float* __restrict__ slab_key,
                                                   float* __restrict__ rec, float* __restrict__ tail,
-                                                  float* __restrict__ tmin, int32_t* __restrict__ bin_reset) {
+                                                  float* __restrict__ tmin, int32_t* __restrict__ bin_reset,
+                                                  const float4 region, const int32_t region_on) {
   const int g0 = blockIdx.x * blockDim.x + threadIdx.x;
   // a frame projected WITHOUT bins must not leave last frame's in the workspace: -1 = "scan for yourself"
   // (bins are only used from 32 k Gaussians up, so the first kBinSupertilesMax threads exist)
@@ -286,6 +287,34 @@ __global__ __launch_bounds__(kThreads) void k_project(int32_t n, const float* __
   const double mx = cam.o[0] - (double)pos[3 * g + 0];
   const double my = cam.o[1] - (double)pos[3 * g + 1];
   const double mz = cam.o[2] - (double)pos[3 * g + 2];
+  // Region cull (round 4, RTGS_TRACE_REGION): a shard that is a compact part of the frame (one sector per rank,
+  // rtgs.parallel.Partition.wedges) only needs the Gaussians that can reach its rectangle.  The ellipsoid lies in
+  // the ball of radius sqrt(3) |q|^2 s_max about its centre; in front of the camera that ball projects inside
+  // [f (x -+ r) / (d +- r)] per axis -- a conservative screen interval from a dozen operations, before the 600 of
+  // the projection proper.  A Gaussian off the rectangle (by more than a pixel) is treated as culled: empty bounds,
+  // no record.  Its distance still enters the slab's depth key, so slabs are visited in the same order and the
+  // shard's pixels equal the whole frame's bit for bit.
+  bool off = false;
+  if (region_on) {
+    const double k2r = (double)rot[4 * g] * rot[4 * g] + (double)rot[4 * g + 1] * rot[4 * g + 1] +
+                       (double)rot[4 * g + 2] * rot[4 * g + 2] + (double)rot[4 * g + 3] * rot[4 * g + 3];
+    const double smr = fmax(fabs((double)scale[3 * g]), fmax(fabs((double)scale[3 * g + 1]), fabs((double)scale[3 * g + 2])));
+    const double rr = 1.7320508075688774 * k2r * smr * (1.0 + 1e-9);
+    // camera-space centre: d_cam = rc^T (mu - o), looking along -z
+    const double xc = -(cam.rc[0] * mx + cam.rc[3] * my + cam.rc[6] * mz);
+    const double yc = -(cam.rc[1] * mx + cam.rc[4] * my + cam.rc[7] * mz);
+    const double dc = cam.rc[2] * mx + cam.rc[5] * my + cam.rc[8] * mz;    // depth along the view direction
+    if (dc - rr > 0.0 && rr < inf) {      // wholly in front of the camera plane (else: keep, the exact test decides)
+      const double fx = 1.0 / cam.inv_fx, fy = 1.0 / cam.inv_fy;
+      const double xh = xc + rr, xl = xc - rr, yh = yc + rr, yl = yc - rr;
+      const double Xhi = fx * xh / (xh >= 0.0 ? dc - rr : dc + rr), Xlo = fx * xl / (xl >= 0.0 ? dc + rr : dc - rr);
+      const double Yhi = fy * yh / (yh >= 0.0 ? dc - rr : dc + rr), Ylo = fy * yl / (yl >= 0.0 ? dc + rr : dc - rr);
+      off = Xhi < (double)region.x - 1.0 || Xlo > (double)region.z + 1.0 || Yhi < (double)region.y - 1.0 ||
+            Ylo > (double)region.w + 1.0;
+    }
+  }
+  if (off) bb = make_float4(kInf, kInf, -kInf, -kInf);
+  if (!off) {
   // quaternion + scale -> inverse covariance, fp64 (utils/quaternion.py:99-121, gaussian.py:86-102)
   double m6[6];
   cov_inverse6(rot + 4 * (size_t)g, scale + 3 * (size_t)g, m6);
@@ -466,7 +495,9 @@ __global__ __launch_bounds__(kThreads) void k_project(int32_t n, const float* __
       bb = make_float4(kInf, kInf, -kInf, -kInf);
     }
   }
-  if (live) {
+  }   // !off
+  if (live && off) bbox[g] = bb;      // (empty bounds: the Gaussian is in no tile's list, its record is never read)
+  if (live && !off) {
     // lower bound of the entry distance t1 over ALL rays: the ellipsoid {d^T Sigma^-1 d <= 3} lies in
     // the ball of radius sqrt(3) |q|^2 s_max about the centre.  k_trace's horizon test skips a
     // candidate whose bound is beyond the 16th entry of every ray of the tile.
@@ -2137,7 +2168,7 @@ static int32_t* tile_bin_of(int32_t* bin_count, size_t nslabs, int width, int he
 // want_bins: build the supertile bins (rtgs_project always asks; rtgs_trace's own projection only when
 // its shard is large enough for them to pay, see trace_impl)
 static int project_impl(const RtgsScene* scene, const RtgsCamera* cam, void* workspace,
-                        size_t workspace_bytes, rtgs_stream_t stream, bool want_bins) {
+                        size_t workspace_bytes, rtgs_stream_t stream, bool want_bins, const float* region = nullptr) {
   if (int rc = validate(scene, cam, workspace, workspace_bytes)) return rc;
   const size_t nn = ((size_t)scene->n + 63) & ~(size_t)63;
   float4* bbox = static_cast<float4*>(workspace);
@@ -2150,19 +2181,20 @@ static int project_impl(const RtgsScene* scene, const RtgsCamera* cam, void* wor
   const bool bins = use_bins(nslabs) && want_bins;
   int32_t* const bin_count = reinterpret_cast<int32_t*>(slab_key_of(slab_bbox, nn) + ((nslabs + 3) & ~3));
   const bool groups = nslabs > kBigSceneSlabs;   // the scenes k_trace / k_bin scan in two levels (Tune<true>)
+  const float4 rgn = region ? make_float4(region[0], region[1], region[2], region[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
   static_assert(kSuper * kSlab == 1024, "k_project<1024>: one block = one group of slabs");
   if (groups)
     hipLaunchKernelGGL(k_project<kSuper * kSlab>, dim3((scene->n + kSuper * kSlab - 1) / (kSuper * kSlab)), dim3(kSuper * kSlab), 0,
                        static_cast<hipStream_t>(stream), scene->n, scene->position, scene->rotation,
                        scene->scale, fc, static_cast<const FrameCam*>(cam->device_pose), bbox, slab_bbox,
                        slab_bbox + nslabs, slab_key_of(slab_bbox, nn), rec, tail, tmin,
-                       (use_bins(nslabs) && !bins) ? bin_count : nullptr);
+                       (use_bins(nslabs) && !bins) ? bin_count : nullptr, rgn, region ? 1 : 0);
   else
     hipLaunchKernelGGL(k_project<256>, dim3((scene->n + 255) / 256), dim3(256), 0,
                        static_cast<hipStream_t>(stream), scene->n, scene->position, scene->rotation,
                        scene->scale, fc, static_cast<const FrameCam*>(cam->device_pose), bbox, slab_bbox,
                        nullptr, slab_key_of(slab_bbox, nn), rec, tail, tmin,
-                       (use_bins(nslabs) && !bins) ? bin_count : nullptr);
+                       (use_bins(nslabs) && !bins) ? bin_count : nullptr, rgn, region ? 1 : 0);
   if (bins) {
     const BinGeom g = bin_geom(cam->width, cam->height);
     float* keys = slab_key_of(slab_bbox, nn);
@@ -2231,6 +2263,8 @@ static int trace_impl(const RtgsScene* scene, const RtgsCamera* cam, const RtgsT
   // an explicit tile list is announced by its flag, not by a non-NULL pointer: a rank whose share is EMPTY has no
   // list to point at, and must render nothing -- not fall back to the arithmetic deal (that was a whole frame written
   // into a one-tile buffer, found by the two-rank rehearsal in round 4)
+  if ((params->flags & RTGS_TRACE_REGION) &&
+      !(params->region[0] <= params->region[2] && params->region[1] <= params->region[3])) return RTGS_EINVAL;   // (NaN too)
   const bool listed = (params->flags & RTGS_TRACE_TILE_LIST) != 0;
   if (listed ? (params->tile_count < 0 || (params->tile_count > 0 && !params->tile_list))
              : (params->tile_list != nullptr || params->tile_step <= 0 || params->tile_first < 0)) return RTGS_EINVAL;
@@ -2241,7 +2275,8 @@ static int trace_impl(const RtgsScene* scene, const RtgsCamera* cam, const RtgsT
   if (local > tile_limit) local = tile_limit;
   if (local <= 0) return RTGS_OK;  // a shard with no tiles
   if (!projected) {
-    if (int rc = project_impl(scene, cam, workspace, workspace_bytes, stream, shard_wants_bins(cam, local))) return rc;
+    if (int rc = project_impl(scene, cam, workspace, workspace_bytes, stream, shard_wants_bins(cam, local),
+                              (params->flags & RTGS_TRACE_REGION) ? params->region : nullptr)) return rc;
   }
 
   const size_t nn = ((size_t)scene->n + 63) & ~(size_t)63;
@@ -2363,6 +2398,7 @@ int rtgs_trace_lists(const RtgsScene* scene, const RtgsCamera* cam, const int32_
   p.tile_order = tile_order;
   p.tile_list = nullptr;
   p.tile_count = 0;
+  p.region[0] = p.region[1] = p.region[2] = p.region[3] = 0.f;
   return trace_impl(scene, cam, &p, nullptr, nullptr, nullptr, 1, workspace, workspace_bytes, projected, INT32_MAX,
                     stream, lists);
 }
@@ -2422,6 +2458,7 @@ int rtgs_render(const RtgsScene* scene, const RtgsCamera* cam, int32_t depth, fl
   p.tile_order = nullptr;
   p.tile_list = nullptr;
   p.tile_count = 0;
+  p.region[0] = p.region[1] = p.region[2] = p.region[3] = 0.f;
   return trace_impl(scene, cam, &p, sample_out, transmittance_out, nullptr, 1, workspace, workspace_bytes,
                     0, (tile_y1 - tile_y0) * tiles_x, stream);
 }
@@ -2489,7 +2526,8 @@ int rtgs_frame_ahead(const RtgsScene* scene, const RtgsCamera* cam, const RtgsTr
   const bool listed = (params->flags & RTGS_TRACE_TILE_LIST) != 0;
   const int32_t local = listed ? params->tile_count
                                : rtgs_num_local_tiles(cam->width, cam->height, params->tile_first, params->tile_step);
-  if (int rc = project_impl(scene, cam, workspace, workspace_bytes, project_stream, shard_wants_bins(cam, local))) return rc;
+  if (int rc = project_impl(scene, cam, workspace, workspace_bytes, project_stream, shard_wants_bins(cam, local),
+                            (params->flags & RTGS_TRACE_REGION) ? params->region : nullptr)) return rc;
   if (hipEventRecord(static_cast<hipEvent_t>(projected_event), ps) != hipSuccess) return RTGS_EDEVICE;
   if (hipStreamWaitEvent(ts, static_cast<hipEvent_t>(projected_event), 0) != hipSuccess) return RTGS_EDEVICE;
   if (int rc = trace_impl(scene, cam, params, out, attenuation_buf, ray_start, 1, workspace, workspace_bytes, 1, INT32_MAX,

@@ -25,6 +25,7 @@ TRACE_COMPACT = 4
 TRACE_SPLIT_ON = 8     # scheduling only: force / forbid two waves per 8x8 tile
 TRACE_SPLIT_OFF = 16
 TRACE_TILE_LIST = 32   # the shard is RtgsTraceParams.tile_list / tile_count (an empty list renders nothing)
+TRACE_REGION = 64      # the shard lies inside RtgsTraceParams.region: its projection skips what cannot reach it
 PEEL_FRESH = 1
 
 LIB_PATH = os.environ.get("RTGS_HIP_LIB") or os.path.join(
@@ -44,7 +45,7 @@ class RtgsCamera(Structure):
 class RtgsTraceParams(Structure):
     _fields_ = [("depth", c_int32), ("t_cutoff", c_float), ("tile_first", c_int32),
                 ("tile_step", c_int32), ("flags", c_uint32), ("tile_order", c_void_p),
-                ("tile_list", c_void_p), ("tile_count", c_int32)]
+                ("tile_list", c_void_p), ("tile_count", c_int32), ("region", c_float * 4)]
 
 
 # name -> (restype, argtypes); mirrors include/rtgs_hip.h one to one.

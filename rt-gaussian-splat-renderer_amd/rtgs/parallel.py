@@ -93,6 +93,7 @@ class Partition:
         for r, t in enumerate(self.tiles):
             self.tile_map[t] = (r << 24) | np.arange(t.size, dtype=np.int32)
         self.arithmetic = name == "round-robin"
+        self.compact = False         # every rank's tiles form one compact part of the frame (wedges): region cull pays
 
     @classmethod
     def round_robin(cls, total: int, world: int) -> "Partition":
@@ -117,6 +118,23 @@ class Partition:
         own = owner[np.arange(total) % cls.PERIOD]
         name = "weighted " + "/".join(str(int(v)) for v in m) + f" of {cls.PERIOD}"
         return cls([np.nonzero(own == r)[0].astype(np.int32) for r in range(sh.size)], total, name)
+
+    @classmethod
+    def wedges(cls, width: int, height: int, tile: int, world: int) -> "Partition":
+        """One compact region per rank: equal-count angular sectors around the image centre (the construction
+        rtgs_launch_order uses per XCD), so that every rank gets the same mix of heavy central and light border
+        tiles of a centre-heavy scene -- and touches only the Gaussians of its sector.  Measured against the
+        interleaved deal in tools/rank_loops.py (DEALS=wedges); not the default: its balance depends on the content."""
+        import numpy as np
+        tx, ty = (width + tile - 1) // tile, (height + tile - 1) // tile
+        t = np.arange(tx * ty)
+        ang = np.arctan2(((t // tx) + 0.5) * tile - 0.5 * height, ((t % tx) + 0.5) * tile - 0.5 * width)
+        order = np.argsort(ang, kind="stable")
+        owner = np.empty(t.size, dtype=np.int64)
+        owner[order] = (np.arange(t.size) * world) // t.size
+        part = cls([np.nonzero(owner == r)[0].astype(np.int32) for r in range(world)], t.size, f"{world} wedges")
+        part.compact = True
+        return part
 
     def shares(self):
         return [c / self.total for c in self.counts]
@@ -290,11 +308,20 @@ class HipBackend:
             self._orders[key] = torch.from_numpy(o).to(self.device)
         return self._orders[key]
 
-    def shard(self, tiles):
-        """Device copies of an explicit tile list and of its launch order: what ``trace(tile_list=...)`` takes."""
+    def shard(self, tiles, region: bool = False):
+        """Device copies of an explicit tile list and of its launch order: what ``trace(shard=...)`` takes.
+        ``region=True``: also the rectangle of pixel-centre offsets that contains the tiles
+        (``RtgsTraceParams.region``: the shard's projection then skips the Gaussians that cannot reach it)."""
         import numpy as np
         nat = self.nat
         tiles = np.ascontiguousarray(tiles, dtype=np.int32)
+        rect = None
+        if region and tiles.size:
+            T, tx = self.tile, (self.width + self.tile - 1) // self.tile
+            i0, j0 = (tiles % tx) * T, (tiles // tx) * T
+            rect = (float(i0.min()) + 0.5 - 0.5 * self.width, float(j0.min()) + 0.5 - 0.5 * self.height,
+                    float(np.minimum(i0 + T, self.width).max()) - 0.5 - 0.5 * self.width,
+                    float(np.minimum(j0 + T, self.height).max()) - 0.5 - 0.5 * self.height)
         order = None
         if self.use_tile_order and tiles.size:
             o = np.empty(tiles.size, dtype=np.int32)
@@ -302,7 +329,19 @@ class HipBackend:
                                                    0 if self.tile_order_mode == "centre" else 1, o.ctypes.data)
             nat.check(min(got, 0), "rtgs_launch_order_list")
             order = torch.from_numpy(o).to(self.device)
-        return dict(list=torch.from_numpy(tiles).to(self.device), count=int(tiles.size), order=order)
+        return dict(list=torch.from_numpy(tiles).to(self.device), count=int(tiles.size), order=order, region=rect)
+
+    def shard_params(self, shard, flags: int):
+        """RtgsTraceParams of an explicit shard (``shard()``)."""
+        import ctypes
+        nat = self.nat
+        flags |= nat.TRACE_TILE_LIST
+        rect = shard.get("region")
+        if rect is not None:
+            flags |= nat.TRACE_REGION
+        return nat.RtgsTraceParams(self.depth, self.t_cutoff, 0, 1, flags, nat.ptr(shard["order"]),
+                                   nat.ptr(shard["list"]) if shard["count"] else None, shard["count"],
+                                   (ctypes.c_float * 4)(*(rect or (0.0, 0.0, 0.0, 0.0))))
 
     def alloc(self, *shape):
         return torch.zeros(shape, dtype=torch.float32, device=self.device)
@@ -332,8 +371,7 @@ class HipBackend:
         if split is not None:
             flags |= nat.TRACE_SPLIT_ON if split else nat.TRACE_SPLIT_OFF
         if shard is not None:      # an explicit tile list (``shard()``) instead of the (first, step) deal
-            params = nat.RtgsTraceParams(self.depth, self.t_cutoff, 0, 1, flags | nat.TRACE_TILE_LIST, nat.ptr(shard["order"]),
-                                         nat.ptr(shard["list"]) if shard["count"] else None, shard["count"])
+            params = self.shard_params(shard, flags)
         else:
             order = self.tile_order(tile_first, tile_step) if self.use_tile_order else None
             params = nat.RtgsTraceParams(self.depth, self.t_cutoff, tile_first, tile_step, flags,
@@ -511,6 +549,8 @@ class TileParallelRenderer:
         self.TILE = int(b.tile)
         self.total_tiles = tiles_of(b.width, b.height, self.TILE)
         self.calibration = None
+        if isinstance(partition, str) and partition == "wedges":
+            partition = Partition.wedges(b.width, b.height, self.TILE, self.world)
         if isinstance(partition, str) and partition == "auto":
             partition = None
             if self.world > 1:
@@ -530,7 +570,8 @@ class TileParallelRenderer:
         # any other deal: this rank's tile list (device), the frame's tile -> (rank, slot) map (destination)
         self._shard = self._tile_map = None
         if not partition.arithmetic:
-            self._shard = b.shard(partition.tiles[self.rank]) if hasattr(b, "shard") else dict(tiles=partition.tiles[self.rank])
+            self._shard = (b.shard(partition.tiles[self.rank], region=partition.compact) if hasattr(b, "shard")
+                           else dict(tiles=partition.tiles[self.rank]))
             if self.world == 1 or self.rank == self.dst:
                 self._tile_map = b.to_device(partition.tile_map) if hasattr(b, "to_device") else partition.tile_map
         if frames_in_flight is None:
@@ -603,9 +644,7 @@ class TileParallelRenderer:
 
         if self._shard is not None:
             order = self._shard["order"]
-            params = nat.RtgsTraceParams(b.depth, b.t_cutoff, 0, 1, nat.TRACE_COMPACT | nat.TRACE_TILE_LIST, nat.ptr(order),
-                                         nat.ptr(self._shard["list"]) if self._shard["count"] else None,
-                                         self._shard["count"])
+            params = b.shard_params(self._shard, nat.TRACE_COMPACT)
         else:
             order = b.tile_order(self.rank, self.world) if (b.use_tile_order and self.local_tiles) else None
             params = nat.RtgsTraceParams(b.depth, b.t_cutoff, self.rank, self.world, nat.TRACE_COMPACT, nat.ptr(order))

@@ -58,6 +58,14 @@ def test_explicit_unequal_shares_cross_the_point_to_point_exchange():
     assert sum(tiles) == 1900 and 0.2 < tiles[1] / 1900 < 0.3
 
 
+def test_the_sector_deal_with_its_region_cull_verifies_through_the_real_exchange():
+    out, line = _run(["--gpus", "2", "--backend", "gloo", "--same-device", "--steps", "4", "--warmup", "1",
+                      "--config", "c2", "--partition", "wedges"])
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert line["verified"] is True and "2 wedges" in line["config"]["parallelism"]
+    assert line["per_rank"]["local_tiles"] == [950, 950]
+
+
 def test_launched_by_torch_distributed_run_it_is_a_rank_as_before():
     # the driver's other launch form: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...
     import socket

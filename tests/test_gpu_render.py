@@ -821,19 +821,20 @@ def test_c3_full_size_sharded_equals_whole(c3):
 
 def _weighted_shards_image(scene, camera, depth, shares, split=None):
     """Every rank's shard of an unequal deal rendered on this GPU (explicit tile lists, compact buffers) and
-    scattered by rtgs_untile_map: what the destination of a weighted tile-parallel frame ends up with."""
+    scattered by rtgs_untile_map: what the destination of a weighted tile-parallel frame ends up with.
+    shares = ("wedges", n): one compact sector per rank, each shard projected with the region cull."""
     from rtgs.parallel import HipBackend, Partition
     hb = HipBackend(scene, camera, depth)
     total = nat.lib().rtgs_num_tiles(hb.width, hb.height)
-    part = Partition.weighted(total, shares)
     T = nat.tile_size()
+    part = Partition.wedges(hb.width, hb.height, T, shares[1]) if shares[0] == "wedges" else Partition.weighted(total, shares)
     bufs = []
     for r in range(part.world):
         if not part.counts[r]:
             bufs.append(None)
             continue
         out = torch.full((part.counts[r], T, T, 3), -7.0, dtype=torch.float32, device="cuda")
-        hb.trace(out, 0, 1, compact=True, shard=hb.shard(part.tiles[r]), split=split)
+        hb.trace(out, 0, 1, compact=True, shard=hb.shard(part.tiles[r], region=part.compact), split=split)
         bufs.append(out)
     image = torch.full((hb.width, hb.height, 3), -9.0, dtype=torch.float32, device="cuda")
     hb.untile_map(bufs, part.counts, hb.to_device(part.tile_map), image)
@@ -845,9 +846,10 @@ def test_c3_full_size_weighted_shards_equal_whole(c3):
     # the link-aware deal (the destination keeps more than its 1/N) is bitwise the whole frame
     arrays, cam, depth, whole = c3
     scene, camera, _ = U.build(arrays, cam)
-    for shares, split in (((0.77, 0.23), None), ((0.31,) + (0.0986,) * 7, None), ((3, 0, 1, 2), True)):
+    for shares, split in (((0.77, 0.23), None), ((0.31,) + (0.0986,) * 7, None), ((3, 0, 1, 2), True),
+                          (("wedges", 8), None), (("wedges", 3), True)):
         image, part = _weighted_shards_image(scene, camera, depth, shares, split)
-        assert max(part.counts) > 2 * min(c for c in part.counts if c) or len(shares) == 2
+        assert part.compact or max(part.counts) > 2 * min(c for c in part.counts if c) or len(shares) == 2
         assert torch.equal(image, whole), f"shares {shares}"
 
 
@@ -885,6 +887,9 @@ def test_c5_full_size_weighted_shards_equal_whole(c5):
     image, part = _weighted_shards_image(scene, camera, depth, (0.3,) + (0.1,) * 7)
     assert part.counts[0] > 2.5 * part.counts[-1]
     assert torch.equal(image, whole)
+    # one compact sector per rank, every shard's projection culled to its rectangle (RTGS_TRACE_REGION): same bits
+    image, part = _weighted_shards_image(scene, camera, depth, ("wedges", 8))
+    assert part.compact and torch.equal(image, whole)
 
 
 def test_c5_two_wave_form_is_bitwise_identical_on_a_shard(c5):

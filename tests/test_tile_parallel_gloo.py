@@ -90,6 +90,8 @@ def _worker(rank, world, port, frames, q, in_flight=2, shares=None):
         assert r.total_tiles == tiles_of(W, H, TILE) == 9
         if shares is None:
             assert r.partition.arithmetic and r.local_tiles == local_tile_count(9, rank, world)
+        elif shares == "wedges":
+            assert r.partition.compact and not r.partition.arithmetic and sum(r.partition.counts) == 9
         elif shares == "auto":
             assert r.calibration is not None and abs(sum(r.calibration["shares"]) - 1) < 1e-9
             assert sum(r.partition.counts) == 9
@@ -176,7 +178,7 @@ def test_launch_orders_are_permutations_and_give_every_xcd_one_wedge():
 
 
 @pytest.mark.parametrize("world,frames,in_flight,shares", [(2, 3, 2, (3, 1)), (3, 4, 2, (5, 1, 3)), (3, 2, 3, (5, 0, 1)),
-                                                             (2, 5, 1, (1, 7)), (2, 3, 2, "auto")])
+                                                             (2, 5, 1, (1, 7)), (2, 3, 2, "auto"), (3, 3, 2, "wedges")])
 def test_unequal_shares_reassemble_on_rank0(world, frames, in_flight, shares):
     # the link-aware deal -- every rank its own share of the tiles (a rank may have none), each shard's
     # own bytes point to point, the destination's own shard scattered from where it was traced; "auto" runs the

@@ -5,7 +5,7 @@ PROJECTION -- the frame time with one peer's bytes crossing an xGMI link at an a
 link-aware deal come from rtgs.parallel.balanced_share with the exchange time that rate implies (on hardware the
 renderer measures it: TileParallelRenderer(partition="auto")).
 
-usage: python tools/rank_loops.py [cfg ...]    env: WORLDS="2 4 8"  LINK_GBS="50 64 77"  F=2"""
+usage: python tools/rank_loops.py [cfg ...]    env: WORLDS="2 4 8"  LINK_GBS="50 64 77"  F=2  DEALS=wedges (also the sector deal)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "rt-gaussian-splat-renderer_amd"), ROOT]
@@ -47,6 +47,8 @@ for name in (sys.argv[1:] or ["c3", "c5"]):
         eq = TileParallelRenderer(scene, camera, depth=cfg.depth, rank=0, world=world, gather_fn=_no_gather, frames_in_flight=F)
         t_shard = loop_us(eq, n); eq.close()
         deals = [("equal", None, None)]
+        if "wedges" in os.environ.get("DEALS", ""):
+            deals.append(("wedges (one compact sector per rank)", "wedges", None))
         for gbs in links:
             t_x = frame_bytes / world / (gbs * 1e3)           # us for one 1/N shard over one link
             x = balanced_share(world, t_shard, t_frame, t_x)
@@ -54,7 +56,9 @@ for name in (sys.argv[1:] or ["c3", "c5"]):
                 sh = [(1 - x) / (world - 1)] * world; sh[0] = x
                 deals.append((f"weighted for {gbs:.0f} GB/s (x = {x:.2f})", sh, gbs))
         for label, shares, gbs in deals:
-            part = Partition.round_robin(total, world) if shares is None else Partition.weighted(total, shares)
+            part = (Partition.round_robin(total, world) if shares is None else
+                    Partition.wedges(cfg.width, cfg.height, nat.tile_size(), world) if isinstance(shares, str) else
+                    Partition.weighted(total, shares))
             per = []
             for rank in range(world):
                 r = TileParallelRenderer(scene, camera, depth=cfg.depth, rank=rank, world=world, gather_fn=_no_gather,
