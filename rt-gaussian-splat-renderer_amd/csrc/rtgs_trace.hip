@@ -1069,6 +1069,9 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   const int32_t* const bin = a.bin_list + (size_t)bin_at * a.bin_stride;
   // this tile's own list (k_bin wrote it iff it wrote the supertile's bin): the count and every thread's entry
   // are loaded together with bin_n above -- ONE round trip instead of bin count -> bin ids -> slab bounds
+  // (when the frame's bins were NOT built -- a small shard -- these two loads read whatever the region
+  // holds: in bounds, and ignored, `binned` below is false then; guarding them with `binned` would put them behind
+  // bin_n's round trip again)
   int tb_n = -1, tb_id = 0;
   if constexpr (RTGS_TILE_BINS != 0) {
     if (a.tile_bin) {
@@ -1596,8 +1599,8 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
 
   // The next entry of ONE ray beyond distance sf, found by the whole wave: every lane takes one Gaussian of a
   // slab that covers the pixel and evaluates it for THAT pixel with the candidate loop's own arithmetic
-  // (pair_eval); of exactly tied entries the lower Gaussian index wins.  Wave-uniform results; false = the
-  // ray misses.  Cold code: only the tie fix-up (below) calls it.
+  // (pair_eval); of exactly tied entries the one that would have arrived first wins.  Wave-uniform results; false =
+  // the ray misses.  Cold code: only the tie fix-up (below) calls it.
   [[maybe_unused]] auto find_next = [&](float Xf, float Yf, float dlf, float sf, unsigned& t_out, unsigned& g_out, float& w_out) -> bool {
     const int n_g = ea->n, nsl = (n_g + kSlab - 1) / kSlab;
     // the tile's own depth-sorted slab list when the frame has one, else every slab
@@ -1613,7 +1616,10 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
         if (c >= 0) { tbl = tb + 1; nlist = c; }
       }
     }
-    unsigned bt = ~0u, bg = ~0u;   // this lane's best (t1 bits, Gaussian) beyond sf
+    // Of exactly tied entries the one that would have ARRIVED first wins, as in the lists: slabs are visited by
+    // (depth key, slab id), a slab's members in index order -- whatever order this search meets them in
+    const float* const skey = reinterpret_cast<const float*>(slab_bbox + nsl + (nsl + kSuper - 1) / kSuper);
+    unsigned bt = ~0u, bk = ~0u, bg = ~0u;   // this lane's best (t1 bits, slab key bits, Gaussian) beyond sf
     float bw = 0.f;
     for (int base = 0; base < nlist; base += kWave) {
       const int li = base + lane;
@@ -1628,21 +1634,24 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
       while (sm) {
         const int sb_ = __builtin_ctzll(sm);
         sm &= sm - 1ull;
-        const int g = __builtin_amdgcn_readlane(sl, sb_) * kSlab + lane;
+        const int slab_i = __builtin_amdgcn_readlane(sl, sb_);
+        const int g = slab_i * kSlab + lane;
         if (g < n_g) {
           const float4 gb = bbox[g];
           if (gb.x <= Xf && gb.z >= Xf && gb.y <= Yf && gb.w >= Yf) {
             float w1;
             const unsigned tb1 = pair_eval(rec, tail, g, Xf, Yf, dlf, sf, w1);
-            if (tb1 < bt || (tb1 == bt && (unsigned)g < bg)) { bt = tb1; bg = (unsigned)g; bw = w1; }
+            const unsigned kb1 = __float_as_uint(skey[slab_i]);     // (keys are >= 0 or +inf: their bits order like them)
+            if (tb1 < bt || (tb1 == bt && (kb1 < bk || (kb1 == bk && (unsigned)g < bg)))) { bt = tb1; bk = kb1; bg = (unsigned)g; bw = w1; }
           }
         }
       }
     }
     const unsigned tmin1 = wave_umin(bt);
     if (tmin1 >= kEmpty) return false;
-    const unsigned gmin = wave_umin(bt == tmin1 ? bg : ~0u);
-    const int wl = __builtin_ctzll(__builtin_amdgcn_ballot_w64(bt == tmin1 && bg == gmin));
+    const unsigned kmin = wave_umin(bt == tmin1 ? bk : ~0u);
+    const unsigned gmin = wave_umin(bt == tmin1 && bk == kmin ? bg : ~0u);
+    const int wl = __builtin_ctzll(__builtin_amdgcn_ballot_w64(bt == tmin1 && bk == kmin && bg == gmin));
     t_out = tmin1;
     g_out = gmin;
     w_out = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(bw), wl));

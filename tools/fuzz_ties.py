@@ -55,8 +55,8 @@ for seed in range(40_000, 40_000 + n_cases):
     tb.sample_all(depth)
     torch.cuda.synchronize()
     # (robust pixels: where two DIFFERENT Gaussians have bit-identical fp32 entry distances -- flagged fragile by the
-    # oracle -- the list keeps the first to arrive and the fix-up's search the lower index: either is the reference's
-    # "one of them", scene.py:433, but they need not be the same one)
+    # oracle -- one of them is composited, the first to arrive, and which slab arrives first depends on how the scene
+    # is laid out in memory: the twins re-shuffle that, as another BVH would in the reference)
     twin_gap = float(np.abs(tb.sample_buf.cpu().numpy().reshape(-1, 3) - got).max(axis=1)[solid_pre].max()) if solid_pre.any() else 0.0
     if twin_gap > 1e-6:
         bad.append((seed, "twins change the image", twin_gap, n, idx.size, w, h, depth, mode))
