@@ -85,6 +85,17 @@ namespace {
 // instructions two thirds of the issue, so a cut of x % of the VALU count returns about 0.4 x % of the
 // time -- which is what each of the experiments above and the macro-tile bins (scan phase 7.7 k -> 7.2 k
 // cycles: 0.1347 -> 0.1317) delivered.
+// Round 4 (DESIGN.md section 4 has the numbers): new -- the tie fix-up at the end of k_trace (a ray whose 16-slot list
+// lost entries to exactly tied twins peels on, `depth` DISTINCT entry distances as the reference composites them), the
+// list form (kList: the sorted distinct entries of every ray go to memory, k_peel composites one per call: the viewer's
+// sample() x 16 from one traversal), explicit tile lists and the region cull of k_project (any partition of the frame
+// over the ranks; one compact sector per rank skips most of the projection), k_bin without scratch, k_project<1024>
+// instead of k_super_bbox.  Measured and dropped again: SH coefficients staged in LDS, per wave and list position
+// (c3 + SH 0.291 -> 0.325 ms) and once per workgroup (0.290 -> 0.288 with 97.5 % of the entries shaded from LDS; 0.2685
+// with nothing fetched at all: the 180 B every lane reads per entry cost the same from either memory); explicit fmaf
+// chains in the SH gather (141 VGPRs at 1 M Gaussians); the next frame's projection on a stream of its own, also at
+// the lowest priority (rtgs_frame_ahead: 0.1502 -> 0.1542 ms per c3 frame: a dependency across two hardware queues
+// costs more than the 17 us of kernels it hides).
 #ifndef RTGS_STAMPS
 #define RTGS_STAMPS 0     // diagnostic build: per-phase s_memtime stamps of wave 0 into the buffer
 #endif                    // passed as attenuation_buf (8 x u64 per block); never quote its run time
