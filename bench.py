@@ -531,6 +531,12 @@ def rank_main(args) -> int:
             except Exception as exc:   # the honesty columns must never break the headline
                 counts = {"error": repr(exc)}
         tests = counts.get("tests_executed") if counts else None
+        # what the issue-slot fraction does not say: of the lanes a wave spends on a candidate, how
+        # many had a hit, and of those of an insertion-network run, how many inserted (counting build, same frame)
+        lanes = None
+        if counts and counts.get("wave_candidates") and counts.get("insertion_network_runs"):
+            lanes = {"conic_tests_with_a_hit": counts["ray_hits"] / (64.0 * counts["wave_candidates"]),
+                     "insertion_runs_that_insert": counts["ray_insertions"] / (64.0 * counts["insertion_network_runs"])}
         lds_bps = lds_gbs * 1e9 if lds_gbs else None
         base_metric = "Mrays/s at 1920x1080, 100k Gaussians; achieved HBM GB/s vs peak"
         metric = base_metric if (cfg.width, cfg.height, cfg.n) == (1920, 1080, 100_000) else \
@@ -575,7 +581,7 @@ def rank_main(args) -> int:
                          "tests_executed": tests, "tests_brute_force": cfg.rays * cfg.n,
                          "cull_rate": (tests / (cfg.rays * cfg.n)) if tests else None,
                          "tests_per_s": (tests / (trace_ms * 1e-3)) if tests else None,
-                         "counts": counts,
+                         "counts": counts, "useful_lane_share": lanes,
                          "lds_bytes_per_s": lds_bps, "lds_insts_per_launch": pc["lds"],
                          "note": "bound = the resource with the highest fraction of its peak among fractions{}: valu = "
                                  "SQ_INSTS_VALU / (1024 SIMDs x 2.4 GHz / 2); vmem-L1 = TCP_TOTAL_CACHE_ACCESSES_sum x 64 B / "
