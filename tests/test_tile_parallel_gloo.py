@@ -217,3 +217,40 @@ def test_partitions_cover_every_tile_once_and_follow_the_shares():
     # at the balance point the destination's trace time equals one peer's transfer time
     c = (150e-6 - 80e-6) / 0.5; p0 = 80e-6 - c / 2
     assert abs((p0 + c * x2) - 200e-6 * 2 * (1 - x2)) < 1e-9
+
+
+def test_partition_properties_hypothesis():
+    # any shares, any frame: a partition (every tile once), shares honoured to a residue, the map inverts the lists;
+    # the balanced share grows with the exchange time and never leaves [1/N, 1]
+    import numpy as np
+    from hypothesis import given, settings, strategies as st
+    from rtgs.parallel import Partition, balanced_share
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.integers(1, 40_000), st.lists(st.floats(0.0, 10.0), min_size=1, max_size=9).filter(lambda v: sum(v) > 1e-3))
+    def check(total, shares):
+        p = Partition.weighted(total, shares)
+        assert sum(p.counts) == total and len(p.tiles) == len(shares)
+        owner = p.tile_map >> 24
+        for r, t in enumerate(p.tiles):
+            assert np.all(owner[t] == r) and np.all(np.diff(t) > 0)
+            assert np.array_equal(p.tile_map[t] & 0xFFFFFF, np.arange(t.size))
+        want = np.array(shares) / sum(shares)
+        if total >= 64 * 50:
+            assert np.abs(np.array(p.shares()) - want).max() <= 1.0 / Partition.PERIOD + 64.0 / total
+
+    check()
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.integers(2, 16), st.floats(1e-6, 1e-3), st.floats(1.0, 8.0), st.floats(0.0, 1e-2), st.floats(0.0, 1e-2))
+    def share(n, t_shard, ratio, tx1, tx2):
+        t_frame = t_shard * ratio
+        lo, hi = sorted((tx1, tx2))
+        a, b = balanced_share(n, t_shard, t_frame, lo), balanced_share(n, t_shard, t_frame, hi)
+        assert 1.0 / n - 1e-12 <= a <= b + 1e-12 <= 1.0 + 1e-12
+
+    share()
+
+    for (w, h, world) in [(1920, 1080, 8), (3840, 2160, 8), (800, 600, 3), (33, 17, 2)]:
+        p = Partition.wedges(w, h, 16, world)
+        assert p.compact and sum(p.counts) == p.total and max(p.counts) - min(p.counts) <= 1
