@@ -90,12 +90,12 @@ namespace {
 // list form (kList: the sorted distinct entries of every ray go to memory, k_peel composites one per call: the viewer's
 // sample() x 16 from one traversal), explicit tile lists and the region cull of k_project (any partition of the frame
 // over the ranks; one compact sector per rank skips most of the projection), k_bin without scratch, k_project<1024>
-// instead of k_super_bbox.  Measured and dropped again: SH coefficients staged in LDS, per wave and list position
-// (c3 + SH 0.291 -> 0.325 ms) and once per workgroup (0.290 -> 0.288 with 97.5 % of the entries shaded from LDS; 0.2685
-// with nothing fetched at all: the 180 B every lane reads per entry cost the same from either memory); explicit fmaf
-// chains in the SH gather (141 VGPRs at 1 M Gaussians); the next frame's projection on a stream of its own, also at
-// the lowest priority (rtgs_frame_ahead: 0.1502 -> 0.1542 ms per c3 frame: a dependency across two hardware queues
-// costs more than the 17 us of kernels it hides).
+// instead of k_super_bbox; SH staging per workgroup for the SH forms of scenes up to 262 k Gaussians (kStage: c3 + SH
+// 0.2905 -> 0.2595 ms).  Measured and dropped again: SH coefficients staged per wave and list position (0.291 -> 0.325
+// ms); the per-workgroup staging for the 1 M-Gaussian form (129 VGPRs: c5 1.293 -> 1.42 capped at 128) and with slots 48
+// floats apart (four-way bank conflicts: no gain at all); explicit fmaf chains in the 1 M-Gaussian form's gather (141
+// VGPRs); the next frame's projection on a stream of its own, also at the lowest priority (rtgs_frame_ahead: 0.1502 ->
+// 0.1542 ms per c3 frame: a dependency across two hardware queues costs more than the 17 us of kernels it hides).
 #ifndef RTGS_STAMPS
 #define RTGS_STAMPS 0     // diagnostic build: per-phase s_memtime stamps of wave 0 into the buffer
 #endif                    // passed as attenuation_buf (8 x u64 per block); never quote its run time
@@ -131,6 +131,10 @@ namespace {
 #define RTGS_TIER 8       // insertions touch only the first RTGS_TIER slots while slot RTGS_TIER-1 is empty in every lane
 #endif                    // (best of 4 / 6 / 8 / 10 / 12; without the tiers c3 0.1634 -> 0.1545 ms)
 
+#ifndef RTGS_SH_STAGE
+#define RTGS_SH_STAGE 1   // SH forms of scenes up to 262 k Gaussians: the 16x16 tile's referenced Gaussians' coefficients are
+#endif                    // fetched ONCE per workgroup into LDS and read per lane from there (k_trace, "SH staging"): c3 + SH
+                          // 0.2905 -> 0.2617 ms.  0: every lane gathers its entries' coefficients from memory
 #ifndef RTGS_SLAB_ITERS
 #define RTGS_SLAB_ITERS 2
 #endif
@@ -920,8 +924,7 @@ __device__ __forceinline__ unsigned pair_eval(const float4* __restrict__ rec, co
 // `depth` final entries -- a wave ballot skips the rest of the round.  Exact: a terminated ray
 // composites nothing behind those entries, so the image equals the compositing-only cut-off's.
 // colour += sum_q Y_q * sh_q (gaussian.py:165-181) in explicit fma chains: the single-entry paths (listed peel, tie
-// fix-up).  The list gathers keep a `+=` form the compiler contracts as it likes (within 1 ulp per term of this): with
-// explicit fmaf the 1 M-Gaussian form needs 141 VGPRs instead of 125 (c5 1.303 -> 1.542 ms, c3 + SH 0.291 -> 0.301)
+// fix-up) and the list forms of scenes up to 262 k Gaussians; the 1 M-Gaussian list forms keep `+=` (within 1 ulp per term of this)
 __device__ __forceinline__ void sh_add(float4& co, const float (&Y)[RTGS_SH_COEFFS], const float* __restrict__ sp) {
 #pragma unroll
   for (int q = 0; q < RTGS_SH_COEFFS; ++q) {
@@ -971,7 +974,32 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   // surviving slab ids: 16 bits are enough below kBigSceneSlabs (4 096) slabs
   using SlabId = typename std::conditional<kBig, int, unsigned short>::type;
   static_assert(kBig || kBigSceneSlabs <= 65536, "slab ids of small scenes are stored in 16 bits");
-  __shared__ SlabId s_slab[kSlabCap];
+  // SH staging (round 4, kStage): ONE staging pass per WORKGROUP for the SH forms of scenes up to 262 k Gaussians.  The
+  // 16x16 tile's referenced Gaussians (40-60: neighbouring 8x8 tiles share half of theirs; up to kStageSlots of them)
+  // are identified by their position in the tile's survivor list -- the list entries of these forms carry that
+  // position instead of the Gaussian index, made absolute (kAbs) before a list refill --, deduplicated by a byte map
+  // over the list, fetched once by LDS-DMA (lane q < 45 brings coefficient q) and read per lane by all four waves.
+  // Slots are 52 floats apart: slot s starts at bank (52 s) mod 64 = 0, 52, 40, 28, ..., so sixteen slots' b128 reads
+  // tile all 64 banks (48 apart they pile onto four: c3 + SH 0.2905 -> 0.2901 ms with 48, 0.2713 with 52, 0.2617 with 96
+  // slots instead of 64).  The staging area shares its LDS with the slab list and the group list, which are dead once
+  // a tile's last round of expansion is behind its barrier.  Not for the 1 M-Gaussian form: its 129 VGPRs with this
+  // would cost it a wave per SIMD (c5 1.293 -> 1.42 ms capped at 128 with spills).
+  constexpr bool kStage = RTGS_SH_STAGE != 0 && kHasSh && !kBig && kK == RTGS_MAX_DEPTH && kSplit == 1 && !kList;
+  constexpr int kStageSlots = 96, kStageStride = 52;
+  constexpr unsigned kAbs = 1u << 31;     // kStage payloads: the id field is a Gaussian index (else: a survivor-list slot)
+  constexpr int kStageBytes = kStageSlots * kStageStride * (int)sizeof(float);
+  static_assert(kStageSlots < 255, "staging slots are bytes, 0xFF = none");
+  constexpr int kSlabBytes = (kSlabCap * (int)sizeof(SlabId) + 15) & ~15;
+  constexpr int kSuperInts = (kBig ? TN::kSlabIters * kBlock : 1);
+  constexpr int kMiscBytes = kSlabBytes + kSuperInts * 4 > kStageBytes ? kSlabBytes + kSuperInts * 4 : kStageBytes;
+  __shared__ float4 s_misc[kStage ? kMiscBytes / 16 + 1 : 1];
+  __shared__ SlabId s_slab_own[kStage ? 1 : kSlabCap];
+  SlabId* const s_slab = kStage ? reinterpret_cast<SlabId*>(s_misc) : s_slab_own;
+  // kStage: which survivor-list slots some ray's list refers to (then: their staging slot, 0xFF = none), the
+  // Gaussian of every staging slot
+  __shared__ unsigned char s_ref[kStage ? kListCap : 1];
+  __shared__ int s_stg_g[kStage ? kStageSlots : 1];
+  __shared__ int s_nref[kStage ? 1 + kWavesPerTile : 1];
   // depth keys of the first kSortMax listed slabs: only alive between the scan and the sort, when
   // the survivor pool is idle (every batch ends with a barrier) -- they share its LDS
   constexpr int kSortMax = RTGS_SORT_MAX < kListCap ? RTGS_SORT_MAX : kListCap;   // kListCap floats fit the pool
@@ -985,7 +1013,9 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   __shared__ int s_rcnt[kRegions], s_rmore[kRegions];
   constexpr int kSuperStep = kSlabIters * kBlock;   // slab groups scanned per outer step
   constexpr bool kTwo = kBig;   // two-level slab scan (small scenes: c3 0.260 vs 0.261 ms flat, one barrier more)
-  __shared__ int s_super[kTwo ? kSuperStep : 1];
+  static_assert(kSuperInts == (kTwo ? kSuperStep : 1), "group list size");
+  __shared__ int s_super_own[kStage ? 1 : kSuperInts];
+  int* const s_super = kStage ? reinterpret_cast<int*>(reinterpret_cast<char*>(s_misc) + kSlabBytes) : s_super_own;
   __shared__ int s_wcnt2[2][kWaves];
 
   const int tid = threadIdx.x;
@@ -1071,6 +1101,10 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz: calibrates the shader clock
   st[0] = __builtin_amdgcn_s_memtime();
 #endif
+  if constexpr (kStage) {
+#pragma unroll
+    for (int q = 0; q < kListCap / kBlock; ++q) s_ref[q * kBlock + tid] = 0;   // (ordered before any mark by the scan's barriers)
+  }
   int scnt = 0;  // surviving slabs listed so far: identical in every thread
   int turn = 0;  // kSplit == 2: candidates of this 8x8 tile seen so far (wave-uniform)
   // this tile's supertile bin (k_bin), if the frame has bins and the bin did not overflow
@@ -1288,9 +1322,10 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
 #endif
       // ---- every wave: survivors vs its own 8x8 tile, then exact per-ray tests.  The regions
       // are walked as one list; the next chunk's bounds load while this chunk's candidates run.
-      auto fetch = [&](int c, int& g, float4& wb, float& tm) {
+      auto fetch = [&](int c, int& g, float4& wb, float& tm, [[maybe_unused]] int& ls) {
         const int v = c + lane;
         g = -1;
+        ls = 0;
         tm = 0.f;
         wb = make_float4(kInf, kInf, -kInf, -kInf);
         if (v < total) {
@@ -1301,12 +1336,14 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
             if (v >= base) slot = v - base + (r + 1) * kRegionCap;
           }
           g = s_idx[slot];
+          ls = slot;
           wb = bbox[g];
           if constexpr (kHorizon) tm = tmin[g];
         }
       };
       if (wave_live && total > 0) {
         int g, gnext = -1;
+        [[maybe_unused]] int ls, lsnext = 0;
         float4 wb, wbnext = make_float4(kInf, kInf, -kInf, -kInf);
         float tm, tmnext = 0.f;
         // (only rounds of at least kCutMinChunks chunks are worth it: the check costs about as much as
@@ -1318,13 +1355,13 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
           // bits order like the floats)
           unsigned run = kEmpty;
           for (int c = ((total - 1) / kWave) * kWave; c >= 0; c -= kWave) {
-            int gq; float4 wq; float tq;
-            fetch(c, gq, wq, tq);
+            int gq, lq; float4 wq; float tq;
+            fetch(c, gq, wq, tq, lq);
             run = min(run, wave_umin(gq >= 0 ? __float_as_uint(tq) : kEmpty));
             if (lane == 0) s_smin[wave * kChunksMax + c / kWave] = __uint_as_float(run);
           }
         }
-        fetch(0, g, wb, tm);
+        fetch(0, g, wb, tm, ls);
         for (int c = 0; c < total; c += kWave) {
           if (cut_round && c > 0 && (c & kWave) == 0 && total - c > kWave) {   // every other chunk
             // attenuation through the entries nearer than everything still to come, as the
@@ -1340,7 +1377,9 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
               const bool valid = fin && tb != prev && nh < a.depth;
               prev = tb;
               if (wave_any(valid && !(Tp < a.t_cutoff))) {
-                const float op = fin ? colop[(kidx[k] >> kSlotBits)].w : 0.f;
+                unsigned gk = kidx[k] >> kSlotBits;
+                if constexpr (kStage) gk = (kidx[k] & kAbs) ? (gk & 0x3FFFFFFu) : (unsigned)s_idx[gk & 0x3FFFFFFu];
+                const float op = fin ? colop[gk].w : 0.f;
                 const float alpha = op * exp_m3(s_wl[(kidx[k] & 15u) * kBlock]);
                 if (valid && !(Tp < a.t_cutoff)) { Tp *= 1.0f - alpha; ++nh; }
               }
@@ -1375,7 +1414,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
             // the next chunk's are issued, so nothing inside the candidate loop waits for memory)
             m &= __ballot(tm < __uint_as_float(min(hz, kEmpty)) || hz >= kEmpty);
           }
-          if (c + kWave < total) fetch(c + kWave, gnext, wbnext, tmnext);
+          if (c + kWave < total) fetch(c + kWave, gnext, wbnext, tmnext, lsnext);
 #if RTGS_ABLATE >= 3
           asm volatile("" ::"s"(m));
           m = 0;
@@ -1478,6 +1517,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
               asm volatile("" ::"v"(kn), "v"(wn));
 #else
               unsigned entry = (unsigned)gi;
+              if constexpr (kStage) entry = (unsigned)__builtin_amdgcn_readlane(ls, b);   // the survivor-list slot, see kStage
               if constexpr (kSplit == 2) {
                 // arrival rank of this candidate in the tile's stream, above the index bits: the
                 // merge then orders equal t1 exactly as the one-wave form's arrival order does
@@ -1518,6 +1558,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
           g = gnext;
           wb = wbnext;
           tm = tmnext;
+          if constexpr (kStage) ls = lsnext;
         }
       }
       // everyone is done with the list before the next round, the next scan or (two-wave form) the
@@ -1526,6 +1567,14 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
 #if RTGS_STAMPS
       t_mark = __builtin_amdgcn_s_memtime();
 #endif
+      if constexpr (kStage) {
+        if (more || !last) {   // (rare: a tile whose survivors overflow the list) the slots are about to be reused
+#pragma unroll
+          for (int k = 0; k < kK; ++k)
+            if (!(kidx[k] & kAbs) && key[k] < kEmpty)
+              kidx[k] = kAbs | ((unsigned)s_idx[(kidx[k] >> kSlotBits) & 0x3FFFFFFu] << kSlotBits) | (kidx[k] & kSlotMask);
+        }
+      }
       if (kSplit == 2 || more || !last) __syncthreads();
 #if RTGS_STAMPS
       t_bar += __builtin_amdgcn_s_memtime() - t_mark;
@@ -1721,6 +1770,59 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
     }
   }
 
+  // ---- kStage: the tile's referenced Gaussians' SH coefficients into LDS, once per workgroup ----
+#if RTGS_COUNT
+  if constexpr (kStage) { n_exp = 0; n_scan = 0; }
+#endif
+  if constexpr (kStage) {
+    constexpr unsigned kIdMask = 0x3FFFFFFu;
+    // (a) every ray marks the survivor-list slots its entries name
+#pragma unroll
+    for (int k = 0; k < kK; ++k)
+      if (key[k] < kEmpty && !(kidx[k] & kAbs)) s_ref[(kidx[k] >> kSlotBits) & kIdMask] = 1;
+    __syncthreads();
+    // (b) one wave numbers the marked slots (list order: a function of the tile alone) and notes their Gaussians
+    if (wave == 0) {
+      int n = 0;
+      for (int base = 0; base < kListCap; base += kWave) {
+        const bool r = s_ref[base + lane] != 0;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(r);
+        const int at = n + below(m);
+        s_ref[base + lane] = (r && at < kStageSlots) ? (unsigned char)at : (unsigned char)0xFF;
+        if (r && at < kStageSlots) s_stg_g[at] = s_idx[base + lane];
+        n += __popcll(m);
+      }
+      if (lane == 0) s_nref[0] = n < kStageSlots ? n : kStageSlots;
+    }
+    __syncthreads();
+    // (c) the four waves fetch them: lane q < 45 brings coefficient q of one Gaussian per instruction, straight into LDS
+    {
+      float* const stage = reinterpret_cast<float*>(s_misc);
+      const int n = __builtin_amdgcn_readfirstlane(s_nref[0]);
+      for (int j = wave; j < n; j += kWaves) {
+        const unsigned gl = (unsigned)__builtin_amdgcn_readfirstlane(s_stg_g[j]);
+        if (lane_e < RTGS_SH_COEFFS * 3)
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void*)(sh + (size_t)gl * (RTGS_SH_COEFFS * 3) + lane_e),
+              (__attribute__((address_space(3))) void*)(stage + j * kStageStride), 4, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // (d) every entry learns its staging slot and becomes absolute for the compositing below:
+    // payload = staging slot (0xFF = none) << 24 | Gaussian index << 4 | exponent slot (these forms have n <= 2^18)
+    static_assert(kBigSceneSlabs * kSlab <= (1 << 18), "staged payloads keep the Gaussian index in 18 bits");
+#pragma unroll
+    for (int k = 0; k < kK; ++k) {
+      if (key[k] < kEmpty && !(kidx[k] & kAbs)) {
+        const unsigned id = (kidx[k] >> kSlotBits) & kIdMask;
+        kidx[k] = ((unsigned)s_ref[id] << 24) | ((unsigned)s_idx[id] << kSlotBits) | (kidx[k] & kSlotMask);
+      } else {
+        kidx[k] |= 0xFF000000u;     // (absolute already, or an empty slot: no staging slot)
+      }
+    }
+    __syncthreads();   // every wave's fetches have landed (each waited for its own above)
+  }
+
   float T = 1.f;
 #if !RTGS_STAMPS
   if ((ea->flags & RTGS_TRACE_RESUME) && in_img) T = ea->att[pix];
@@ -1739,7 +1841,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
     const float in = 1.0f / sqrtf(wx * wx + wy * wy + wz * wz);  // gaussian.py:200
     sh_basis(wx * in, wy * in, wz * in, Ysh);
   }
-  [[maybe_unused]] const unsigned idx_mask = kSplit == 2 ? (1u << ea->idx_bits) - 1u : ~0u;
+  [[maybe_unused]] const unsigned idx_mask = kSplit == 2 ? (1u << ea->idx_bits) - 1u : (kStage ? 0x3FFFFu : ~0u);
   int nhit = 0;
   float last_t = 0.f;
   unsigned prev_tbits = 0u;
@@ -1785,23 +1887,58 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
         prev_tbits = tbits;
         float4 co = cog[j];
         if (kHasSh) {
-          if (live) {   // (gathering for every slot, valid or not, to batch the loads: 2.24 vs 2.08 ms on c5)
-            // (records padded to 192 or 256 B and 16-B aligned: c3 + SH 0.310 -> 0.333 / 0.381 ms.  SH per (wave,
-            // insertion event) through scalar loads: 0.289 -> 0.317, c5 1.30 -> 1.99.  Round 4, the coefficients
-            // STAGED IN LDS and read per lane from there, two builds, both bit-identical in their pixels and both
-            // dropped (commits b90b368 and 3c75e8a): per wave and list position (exact dedupe
-            // loop + LDS-DMA, 16 slots in the LDS that is idle by then): c3 + SH 0.291 -> 0.325, c5 1.282 -> 1.713;
-            // per workgroup, once (survivor-list slots as identity, byte-map dedupe, 64 slots, three barriers):
-            // 97.5 % of c3 + SH's entries shaded from LDS and k_trace 0.290 -> 0.288, c5 1.293 -> 1.448 -- and with
-            // NOTHING fetched at all 0.2685 / 1.290.  The gather is not what this phase waits for: a workgroup of
-            // the SH form lives 74 k cycles against 65 k without SH, but only 4 of them fit a CU (125 VGPRs)
-            // instead of 7 (profiles/r04_phase_stamps.txt).)
-            const float* sp = sh + (size_t)gi * (RTGS_SH_COEFFS * 3);
+          // Per entry 45 coefficients, 180 B per lane.  (Records padded to 192 or 256 B and 16-B aligned: c3 + SH 0.310 ->
+          // 0.333 / 0.381 ms.  SH per (wave, insertion event) through scalar loads: 0.289 -> 0.317, c5 1.30 -> 1.99.
+          // Staged per wave and list position instead of per workgroup, commit b90b368: 0.291 -> 0.325 / c5 1.282 ->
+          // 1.713 -- a serial chain per position.)  Forms with the staging (kStage) read them from LDS for the entries
+          // that have a slot; the few that have none -- more than kStageSlots referenced Gaussians in the tile, or
+          // a tile whose survivor list was refilled -- and all other forms gather from memory.  The small-scene forms
+          // fold them in with explicit fma chains from either source, so that their staged and gathering (two-wave,
+          // single-peel) instantiations agree bit for bit; the 1 M-Gaussian forms keep `+=`, which the compiler
+          // contracts as it likes: with explicit fmaf they need 141 VGPRs instead of 125 (c5 1.303 -> 1.542 ms).
+          if constexpr (kStage) {
+            const unsigned ss = kidx[k] >> 24;
+#if RTGS_COUNT   // (counting build: slots 5 / 6 count the entries shaded from the staging / from memory)
+            n_exp += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(live && ss != 0xFFu));
+            n_scan += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(live && ss == 0xFFu));
+#endif
+            if (live) {
+              // four steps of 12 floats (4 coefficients x rgb) from the lane's source: all 45 in flight at once cost 34 VGPRs
+              const float* const lp = reinterpret_cast<const float*>(s_misc) + ss * kStageStride;
+              const float* const gp = sh + (size_t)gi * (RTGS_SH_COEFFS * 3);
 #pragma unroll
-            for (int q = 0; q < RTGS_SH_COEFFS; ++q) {
-              co.x += Ysh[q] * sp[3 * q + 0];
-              co.y += Ysh[q] * sp[3 * q + 1];
-              co.z += Ysh[q] * sp[3 * q + 2];
+              for (int c4 = 0; c4 < 4; ++c4) {
+                float cf[12];
+                if (ss != 0xFFu) {
+                  const float4 v0 = reinterpret_cast<const float4*>(lp)[3 * c4], v1 = reinterpret_cast<const float4*>(lp)[3 * c4 + 1],
+                               v2 = reinterpret_cast<const float4*>(lp)[3 * c4 + 2];
+                  cf[0] = v0.x; cf[1] = v0.y; cf[2] = v0.z; cf[3] = v0.w; cf[4] = v1.x; cf[5] = v1.y; cf[6] = v1.z; cf[7] = v1.w;
+                  cf[8] = v2.x; cf[9] = v2.y; cf[10] = v2.z; cf[11] = v2.w;
+                } else {
+#pragma unroll
+                  for (int q = 0; q < 12; ++q) cf[q] = 12 * c4 + q < RTGS_SH_COEFFS * 3 ? gp[12 * c4 + q] : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  if (4 * c4 + q < RTGS_SH_COEFFS) {
+                    co.x = fmaf(Ysh[4 * c4 + q], cf[3 * q + 0], co.x);
+                    co.y = fmaf(Ysh[4 * c4 + q], cf[3 * q + 1], co.y);
+                    co.z = fmaf(Ysh[4 * c4 + q], cf[3 * q + 2], co.z);
+                  }
+                }
+              }
+            }
+          } else if (live) {   // (gathering for every slot, valid or not, to batch the loads: 2.24 vs 2.08 ms on c5)
+            const float* sp = sh + (size_t)gi * (RTGS_SH_COEFFS * 3);
+            if constexpr (kBig) {
+#pragma unroll
+              for (int q = 0; q < RTGS_SH_COEFFS; ++q) {
+                co.x += Ysh[q] * sp[3 * q + 0];
+                co.y += Ysh[q] * sp[3 * q + 1];
+                co.z += Ysh[q] * sp[3 * q + 2];
+              }
+            } else {
+              sh_add(co, Ysh, sp);
             }
           }
         }

@@ -263,7 +263,7 @@ def test_build_is_keyed_on_the_source_hash_not_on_mtimes(tmp_path):
 NON_DEFAULT_BUILDS = [["-DRTGS_STAMPS=1"], ["-DRTGS_COUNT=1"], ["-DRTGS_BINS=0"], ["-DRTGS_TILE_BINS=0"],
                       ["-DRTGS_ABLATE=1"], ["-DRTGS_ABLATE=2"], ["-DRTGS_ABLATE=3"], ["-DRTGS_ABLATE=4"],
                       ["-DRTGS_CUT_TRAVERSAL=0"], ["-DRTGS_HORIZON=0"], ["-DRTGS_LOOKAHEAD=0"], ["-DRTGS_LOOKAHEAD=2"],
-                      ["-DRTGS_TIER=4"], ["-DRTGS_BINS=0", "-DRTGS_TILE_BINS=0", "-DRTGS_STAMPS=1", "-DRTGS_COUNT=1"]]
+                      ["-DRTGS_TIER=4"], ["-DRTGS_SH_STAGE=0"], ["-DRTGS_BINS=0", "-DRTGS_TILE_BINS=0", "-DRTGS_STAMPS=1", "-DRTGS_COUNT=1"]]
 
 
 def test_every_remaining_kernel_switch_still_compiles():
@@ -287,5 +287,5 @@ def test_every_remaining_kernel_switch_still_compiles():
             assert rc == 0, f"{' '.join(flags)} does not compile:\n{err}"
     text = open(os.path.join(src, "rtgs_trace.hip")).read()
     for gone in ("RTGS_MED3", "RTGS_TWO_LEVEL", "RTGS_SH_ABLATE", "RTGS_ABLATE_PAYLOAD", "RTGS_SKIP_LOWER", "RTGS_FAST_DIV",
-                 "RTGS_COMPOSITE_EXIT", "k_super_bbox(", "RTGS_SH_STAGE", "RTGS_SH_FMA"):
+                 "RTGS_COMPOSITE_EXIT", "k_super_bbox(", "RTGS_SH_FMA", "RTGS_STAGE2"):
         assert gone not in text, gone
