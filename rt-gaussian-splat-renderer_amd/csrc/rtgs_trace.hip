@@ -982,8 +982,9 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   // Slots are 52 floats apart: slot s starts at bank (52 s) mod 64 = 0, 52, 40, 28, ..., so sixteen slots' b128 reads
   // tile all 64 banks (48 apart they pile onto four: c3 + SH 0.2905 -> 0.2901 ms with 48, 0.2713 with 52, 0.2617 with 96
   // slots instead of 64).  The staging area shares its LDS with the slab list and the group list, which are dead once
-  // a tile's last round of expansion is behind its barrier.  Not for the 1 M-Gaussian form: its 129 VGPRs with this
-  // would cost it a wave per SIMD (c5 1.293 -> 1.42 ms capped at 128 with spills).
+  // a tile's last round of expansion is behind its barrier.  Not for the 1 M-Gaussian form (built, with colour + opacity
+  // staged too and 80 slots = what four workgroups per CU leave: c5 1.304 -> 1.459 ms; its tiles name 66.8 distinct
+  // Gaussians on average, 42 % of them more than 80, and a wave with one slot-less lane runs both sources).
   constexpr bool kStage = RTGS_SH_STAGE != 0 && kHasSh && !kBig && kK == RTGS_MAX_DEPTH && kSplit == 1 && !kList;
   constexpr int kStageSlots = 96, kStageStride = 52;
   constexpr unsigned kAbs = 1u << 31;     // kStage payloads: the id field is a Gaussian index (else: a survivor-list slot)
