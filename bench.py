@@ -243,7 +243,8 @@ def profiled_counters(cfg_name, world, src_hash):
     used when the summary carries the hash of the sources this build was made from: a counter of
     another build divided by this build's time is not a measurement."""
     path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{cfg_name}_summary.json")
-    out = {"valu": None, "lds": None, "traffic": None, "tcp": None, "ta_busy": None, "source": None, "stale": None}
+    out = {"valu": None, "lds": None, "traffic": None, "tcp": None, "ta_busy": None, "lds_busy": None, "lds_conflict": None,
+           "source": None, "stale": None}
     if world != 1 or not os.path.exists(path):
         return out
     with open(path) as f:
@@ -259,6 +260,11 @@ def profiled_counters(cfg_name, world, src_hash):
     if pmc.get("TA_TA_BUSY_sum") and pmc.get("GRBM_GUI_ACTIVE"):
         # busy cycles summed over the 256 TAs / (cycles the GPU was active, summed over the 8 XCDs / 8) / 256
         out["ta_busy"] = pmc["TA_TA_BUSY_sum"] / N_CU / (pmc["GRBM_GUI_ACTIVE"] / 8.0)
+    if pmc.get("SQ_LDS_IDX_ACTIVE") and pmc.get("GRBM_GUI_ACTIVE"):
+        # rocprofv3's own LdsUtil: cycles the CUs' LDS pipelines were busy / (active cycles x 256 CUs); wide (b128) reads
+        # and bank conflicts count for what they occupy, which an instruction count x 256 B does not see
+        out["lds_busy"] = pmc["SQ_LDS_IDX_ACTIVE"] / N_CU / (pmc["GRBM_GUI_ACTIVE"] / 8.0)
+        out["lds_conflict"] = (pmc.get("SQ_LDS_BANK_CONFLICT") or 0.0) / pmc["SQ_LDS_IDX_ACTIVE"]
     return out
 
 
@@ -274,7 +280,7 @@ def counted_tests(count_lib, scene, camera, depth):
     out = torch.zeros((w, h, 3), dtype=torch.float32, device="cuda")
     ws = torch.empty(cl.rtgs_workspace_bytes(scene.num_gaussians), dtype=torch.uint8, device="cuda")
     params = nat.RtgsTraceParams(int(depth), 0.0, 0, 1, 0, None)
-    buf = (ctypes.c_ulonglong * 8)()
+    buf = (ctypes.c_ulonglong * 12)()
     nat.check(cl.rtgs_debug_counters(None, 1), "rtgs_debug_counters")
     nat.check(cl.rtgs_trace(scene.native(), camera.native(), params, nat.ptr(out), None, None, 1, nat.ptr(ws),
                             ws.numel(), 0, nat.stream()), "rtgs_trace (counting build)")
@@ -282,7 +288,11 @@ def counted_tests(count_lib, scene, camera, depth):
     c = [int(v) for v in buf]
     return {"wave_candidates": c[0], "wave_candidates_with_a_hit": c[1], "insertion_network_runs": c[2],
             "ray_hits": c[3], "ray_insertions": c[4], "gaussian_bounds_tested": c[5], "slab_bounds_tested": c[6],
-            "waves": c[7], "tests_executed": c[0] * 64}
+            "waves": c[7], "tests_executed": c[0] * 64,
+            # forms with the SH staging (SH scenes up to 262 k Gaussians): entries shaded from LDS / from memory,
+            # distinct Gaussians a workgroup's lists name (mean), workgroups that name more than the 96 staging slots
+            "sh_entries_from_lds": c[8], "sh_entries_from_memory": c[9],
+            "sh_named_gaussians_per_workgroup": (c[10] / (c[7] / 4)) if c[10] else None, "sh_workgroups_over_slots": c[11]}
 
 
 def main(argv=None) -> int:
@@ -517,12 +527,14 @@ def rank_main(args) -> int:
         # no-SH instantiations issue VALU instructions, the SH ones wait for the vector L1's tag pipeline
         fractions = {"valu": (achieved / VALU_PEAK_GINST) if achieved else None,
                      "vmem-L1": (l1_gbs / L1_PEAK_GBS) if l1_gbs else None,
-                     "lds": (lds_gbs / LDS_PEAK_GBS) if lds_gbs else None,
+                     # (the LDS pipelines' busy share when the profile has it: it sees b128 reads and bank conflicts)
+                     "lds": pc["lds_busy"] if pc["lds_busy"] is not None else ((lds_gbs / LDS_PEAK_GBS) if lds_gbs else None),
                      "hbm": (hbm_gbs / HBM_PEAK_GBS) if hbm_gbs else None}
         known = {k: v for k, v in fractions.items() if v is not None}
         bound = max(known, key=known.get) if known else "valu"
         by_bound = {"valu": (achieved, VALU_PEAK_GINST, "G wave64-instr/s"), "vmem-L1": (l1_gbs, L1_PEAK_GBS, "GB/s"),
-                    "lds": (lds_gbs, LDS_PEAK_GBS, "GB/s"), "hbm": (hbm_gbs, HBM_PEAK_GBS, "GB/s")}[bound]
+                    "lds": ((pc["lds_busy"] * LDS_PEAK_GBS) if pc["lds_busy"] is not None else lds_gbs, LDS_PEAK_GBS, "GB/s"),
+                    "hbm": (hbm_gbs, HBM_PEAK_GBS, "GB/s")}[bound]
         # SURVEY 8(d) honesty columns (ii) and (iii): tests actually executed vs rays x N, LDS bytes/s
         counts = None
         if world == 1 and os.path.exists(count_lib):
@@ -569,6 +581,7 @@ def rank_main(args) -> int:
                          "frac": known.get(bound), "fractions": fractions,
                          "valu_achieved_ginst": achieved, "valu_peak_ginst": VALU_PEAK_GINST,
                          "l1_achieved_gbs": l1_gbs, "l1_peak_gbs": L1_PEAK_GBS, "ta_busy_frac": pc["ta_busy"],
+                         "lds_busy_frac": pc["lds_busy"], "lds_bank_conflict_share": pc["lds_conflict"],
                          "tcp_cache_accesses_per_launch": pc["tcp"],
                          "traffic": traffic, "traffic_unit": "HBM bytes per k_trace launch (PMC)",
                          "hbm_achieved_gbs": hbm_gbs, "hbm_peak_gbs": HBM_PEAK_GBS,
@@ -585,7 +598,8 @@ def rank_main(args) -> int:
                          "lds_bytes_per_s": lds_bps, "lds_insts_per_launch": pc["lds"],
                          "note": "bound = the resource with the highest fraction of its peak among fractions{}: valu = "
                                  "SQ_INSTS_VALU / (1024 SIMDs x 2.4 GHz / 2); vmem-L1 = TCP_TOTAL_CACHE_ACCESSES_sum x 64 B / "
-                                 "(256 CUs x 64 B/clk x 2.4 GHz); lds = SQ_INSTS_LDS x 256 B / (256 CUs x 128 B/clk x 2.4 GHz); "
+                                 "(256 CUs x 64 B/clk x 2.4 GHz); lds = SQ_LDS_IDX_ACTIVE / (GRBM_GUI_ACTIVE x 256 CUs), rocprofv3's LdsUtil, of the profiled run "
+                                 "(without that pass: SQ_INSTS_LDS x 256 B / (256 CUs x 128 B/clk x 2.4 GHz)); "
                                  "hbm = (FETCH_SIZE x 2 + WRITE_SIZE) / 8 TB/s; all null when the "
                                  "committed counters are of another source hash.  speedup_vs_streamed_model = "
                                  "SURVEY 8(d)'s every-tile-streams-every-Gaussian byte count / kernel time / 8 TB/s: "

@@ -261,8 +261,10 @@ struct TraceArgs {
 #if RTGS_COUNT
 // [0] candidates a wave evaluated (x 64 lanes = ray-Gaussian conic tests executed), [1] of those with a hit
 // in some lane, [2] insertion-network runs, [3] lanes with a valid hit, [4] lanes that inserted,
-// [5] Gaussian bounds tested by the expansion (lanes), [6] slab bounds tested (lanes), [7] waves
-__device__ unsigned long long g_count[8];
+// [5] Gaussian bounds tested by the expansion (lanes), [6] slab bounds tested (lanes), [7] waves,
+// forms with the SH staging (kStage): [8] entries shaded from LDS, [9] from memory, [10] distinct Gaussians the
+// workgroups' lists named (summed), [11] workgroups that named more than there are staging slots
+__device__ unsigned long long g_count[12];
 #endif
 
 // ------------------------------------------------------------------------------------
@@ -1093,6 +1095,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   const float* const slab_key = reinterpret_cast<const float*>(slab_bbox + nslabs + (nslabs + kSuper - 1) / kSuper);
 #if RTGS_COUNT
   unsigned n_iter = 0, n_pass = 0, n_ins = 0, n_hit_lanes = 0, n_ins_lanes = 0, n_exp = 0, n_scan = 0;
+  [[maybe_unused]] unsigned n_lds = 0, n_mem = 0, n_named = 0, n_over = 0;
 #endif
 #if RTGS_STAMPS
   unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
@@ -1772,9 +1775,6 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   }
 
   // ---- kStage: the tile's referenced Gaussians' SH coefficients into LDS, once per workgroup ----
-#if RTGS_COUNT
-  if constexpr (kStage) { n_exp = 0; n_scan = 0; }
-#endif
   if constexpr (kStage) {
     constexpr unsigned kIdMask = 0x3FFFFFFu;
     // (a) every ray marks the survivor-list slots its entries name
@@ -1794,6 +1794,9 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
         n += __popcll(m);
       }
       if (lane == 0) s_nref[0] = n < kStageSlots ? n : kStageSlots;
+#if RTGS_COUNT
+      if (lane == 0) { n_named = (unsigned)n; n_over = n > kStageSlots ? 1u : 0u; }
+#endif
     }
     __syncthreads();
     // (c) the four waves fetch them: lane q < 45 brings coefficient q of one Gaussian per instruction, straight into LDS
@@ -1899,9 +1902,9 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
           // contracts as it likes: with explicit fmaf they need 141 VGPRs instead of 125 (c5 1.303 -> 1.542 ms).
           if constexpr (kStage) {
             const unsigned ss = kidx[k] >> 24;
-#if RTGS_COUNT   // (counting build: slots 5 / 6 count the entries shaded from the staging / from memory)
-            n_exp += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(live && ss != 0xFFu));
-            n_scan += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(live && ss == 0xFFu));
+#if RTGS_COUNT
+            n_lds += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(live && ss != 0xFFu));
+            n_mem += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(live && ss == 0xFFu));
 #endif
             if (live) {
               // four steps of 12 floats (4 coefficients x rgb) from the lane's source: all 45 in flight at once cost 34 VGPRs
@@ -2002,8 +2005,9 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
 
 #if RTGS_COUNT
   if (lane == 0) {
-    const unsigned v[8] = {n_iter, n_pass, n_ins, n_hit_lanes, n_ins_lanes, n_exp, n_scan, 1u};
-    for (int k = 0; k < 8; ++k) atomicAdd(&g_count[k], (unsigned long long)v[k]);
+    const unsigned v[12] = {n_iter, n_pass, n_ins, n_hit_lanes, n_ins_lanes, n_exp, n_scan, 1u, n_lds, n_mem, n_named, n_over};
+    for (int k = 0; k < 12; ++k)
+      if (v[k]) atomicAdd(&g_count[k], (unsigned long long)v[k]);
   }
 #endif
   if (ea->flags & RTGS_TRACE_COMPACT) {
@@ -2760,7 +2764,7 @@ int rtgs_debug_counters(unsigned long long* host_out, int32_t reset) {
   if (hipDeviceSynchronize() != hipSuccess) return RTGS_EDEVICE;
   if (host_out && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_count), sizeof(g_count)) != hipSuccess) return RTGS_EDEVICE;
   if (reset) {
-    const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long z[sizeof(g_count) / sizeof(g_count[0])] = {};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_count), z, sizeof(z)) != hipSuccess) return RTGS_EDEVICE;
   }
   return RTGS_OK;

@@ -323,6 +323,41 @@ def test_transmittance_cutoff_matches_the_oracle(name, cut):
         assert np.abs(got - full["sample"]).max() > 1e-3
 
 
+@pytest.mark.parametrize("n", [6_000, 60_000])
+def test_sh_staging_with_more_referenced_gaussians_than_slots(n):
+    # the SH forms of scenes up to 262 k Gaussians shade from coefficients staged in LDS once per 16x16 tile (96
+    # slots, csrc/rtgs_trace.hip kStage); entries of a tile that names more Gaussians than that, and of refilled
+    # lists, gather theirs from memory.  A crowd of small translucent Gaussians makes most tiles overflow: the
+    # pixels must equal the oracle's, and -- bit for bit -- the two-wave form's, which gathers everything.
+    import os, sys
+    from oracle import c_oracle
+    arrays = synthetic.make_scene(n, 16 / 9, 99, sh=True)   # (footprints of a few pixels: 140 / 1 000 Gaussians per tile)
+    arrays["opacity"] = (0.15 + 0.3 * arrays["opacity"]).astype(np.float32)
+    cam = synthetic.bench_camera(160, 90)
+    scene, camera, tr = U.build(arrays, cam)
+    tr.trace(16, flags=nat.TRACE_SPLIT_OFF)
+    torch.cuda.synchronize()
+    one = tr.sample_buf.clone()
+    rng = np.random.default_rng(8)
+    pix = np.stack([rng.integers(0, 160, 2000), rng.integers(0, 90, 2000)], axis=-1).astype(np.int32)
+    want = c_oracle.render(arrays, cam, 16, pix)
+    assert want["hits"].mean() > 8
+    U.assert_parity(U.at(one, pix), want, "crowded SH scene")
+    tr.clear_sample()
+    tr.trace(16, flags=nat.TRACE_SPLIT_ON)
+    assert torch.equal(tr.sample_buf, one)
+    # the counting build of the same sources says how many entries were shaded from which source
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    bench.np, bench.torch = np, torch
+    _, count_lib = bench.source_hash()
+    if os.path.exists(count_lib):
+        c = bench.counted_tests(count_lib, scene, camera, 16)
+        staged, gathered = c["sh_entries_from_lds"], c["sh_entries_from_memory"]
+        assert staged > 0 and gathered > 0.05 * (staged + gathered), (staged, gathered)
+
+
 @pytest.mark.parametrize("sh", [False, True])
 def test_cutoff_ends_traversal_on_a_dense_opaque_scene(sh):
     # with t_cutoff > 0 the kernel also stops a tile's TRAVERSAL once every ray is terminated behind

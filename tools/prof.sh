@@ -17,7 +17,8 @@ i=0
 for pass in "TA_TA_BUSY_sum GRBM_GUI_ACTIVE" "TA_FLAT_READ_WAVEFRONTS_sum TA_TOTAL_WAVEFRONTS_sum" \
             "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCP_TOTAL_ACCESSES_sum TCP_GATE_EN1_sum" \
             "TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum" \
-            "SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES"; do
+            "SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES" \
+            "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT"; do
   i=$((i+1))
   timeout -k 10 240 rocprofv3 --pmc $pass --output-format csv -d $OUT/pmc_v$i -- $B "$@" > $OUT/bench_pmc_v$i.log 2>&1 || echo "pass $i ($pass) failed"
   echo "pass $i done" >> $OUT/progress.log
