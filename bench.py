@@ -268,7 +268,7 @@ def profiled_counters(cfg_name, world, src_hash):
     return out
 
 
-def counted_tests(count_lib, scene, camera, depth):
+def counted_tests(count_lib, scene, camera, depth, flags=0):
     """One frame through the COUNTING build of the same sources (-DRTGS_COUNT=1, build.py): how many
     ray x Gaussian conic tests k_trace actually executes (candidates a wave evaluated x 64 lanes),
     hits and insertions.  Outside every timed region; the counting build is never timed."""
@@ -279,7 +279,7 @@ def counted_tests(count_lib, scene, camera, depth):
     w, h = camera.buf_size.x, camera.buf_size.y
     out = torch.zeros((w, h, 3), dtype=torch.float32, device="cuda")
     ws = torch.empty(cl.rtgs_workspace_bytes(scene.num_gaussians), dtype=torch.uint8, device="cuda")
-    params = nat.RtgsTraceParams(int(depth), 0.0, 0, 1, 0, None)
+    params = nat.RtgsTraceParams(int(depth), 0.0, 0, 1, int(flags), None)
     buf = (ctypes.c_ulonglong * 12)()
     nat.check(cl.rtgs_debug_counters(None, 1), "rtgs_debug_counters")
     nat.check(cl.rtgs_trace(scene.native(), camera.native(), params, nat.ptr(out), None, None, 1, nat.ptr(ws),
