@@ -25,12 +25,19 @@ ORACLE_LIB = os.path.join(ROOT, "oracle", "_build", "librtgs_oracle.so")
 HIP_SOURCES = ["rtgs_trace.hip", "rtgs_ops.hip"]
 
 
+# -fno-slp-vectorize: the SLP vectoriser pairs fp32 FMAs into v_pk_fma_f32 with their broadcast operands DUPLICATED into
+# register pairs (15 SH basis values -> 30 VGPRs); without it every k_trace form needs fewer registers and runs faster
+# (round 4: c3 0.1320 -> 0.1285 ms, c5 1.304 -> 1.273, c3 + SH 0.2595 -> 0.2400)
+BASE_FLAGS = ["-O3", "-fno-slp-vectorize", "--offload-arch=gfx950", "-std=c++17"]
+
+
 def source_hash() -> str:
-    """sha256 (16 hex digits) of everything librtgs_hip.so is compiled from: csrc/* and
-    include/rtgs_hip.h.  Stored in the profile summaries under profiles/ so that bench.py can tell
+    """sha256 (16 hex digits) of everything librtgs_hip.so is compiled from: csrc/*,
+    include/rtgs_hip.h and the compiler flags every build shares.  Stored in the profile summaries under profiles/ so that bench.py can tell
     whether a committed counter belongs to the build it is timing."""
     import hashlib
     h = hashlib.sha256()
+    h.update(" ".join(BASE_FLAGS).encode() + b"\0")
     files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".h")))
     for f in files + [os.path.join(ROOT, "include", "rtgs_hip.h")]:
         h.update(os.path.basename(f).encode() + b"\0")
@@ -77,7 +84,7 @@ def _hipcc(out, extra_flags=()):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     srcs, _ = _hip_deps()
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    _run([hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
+    _run([hipcc, *BASE_FLAGS, "-fPIC", "-shared",
           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, *extra_flags, *srcs, "-o", out])
     with open(out + ".srchash", "w") as f:
         f.write(_stamp(extra_flags) + "\n")

@@ -277,7 +277,7 @@ def test_every_remaining_kernel_switch_still_compiles():
     src = os.path.join(ROOT, "rt-gaussian-splat-renderer_amd", "csrc")
 
     def check(flags):
-        out = subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "-Wno-unused-command-line-argument",
+        out = subprocess.run([hipcc, "-O3", "-fno-slp-vectorize", "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "-Wno-unused-command-line-argument",
                               "-I" + os.path.join(ROOT, "include"), "-I" + src, *flags, os.path.join(src, "rtgs_trace.hip")],
                              capture_output=True, text=True, timeout=300)
         return flags, out.returncode, out.stderr[-1500:]

@@ -4,7 +4,7 @@
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/ab; mkdir -p $OUT
 for v in "$@"; do
   name=${v%%:*}; flags=${v#*:}
-  hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared -I$R/include -I$R/rt-gaussian-splat-renderer_amd/csrc $flags \
+  hipcc -O3 -fno-slp-vectorize --offload-arch=gfx950 -std=c++17 -fPIC -shared -I$R/include -I$R/rt-gaussian-splat-renderer_amd/csrc $flags \
      $R/rt-gaussian-splat-renderer_amd/csrc/rtgs_trace.hip $R/rt-gaussian-splat-renderer_amd/csrc/rtgs_ops.hip -o $OUT/lib_$name.so 2>/dev/null || { echo "$name: BUILD FAILED"; continue; }
   if [ -n "$CHECK" ]; then
     RTGS_HIP_LIB=$OUT/lib_$name.so python -m pytest $R/tests -x -q -m gpu -k "golden or stacked or truncation or duplicates or ties or sharded or random or fuzz" > $OUT/check_$name.log 2>&1 \

@@ -2,7 +2,7 @@
 # usage: tools/resources.sh [extra hipcc flags]  -- register / spill / scratch / occupancy table of every kernel in
 # rtgs_trace.hip (clang -Rpass-analysis=kernel-resource-usage), cross-compiled for gfx950: no GPU needed
 R=$(cd "$(dirname "$0")/.." && pwd)
-hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -c -I$R/include -I$R/rt-gaussian-splat-renderer_amd/csrc "$@" \
+hipcc -O3 -fno-slp-vectorize --offload-arch=gfx950 -std=c++17 -fPIC -c -I$R/include -I$R/rt-gaussian-splat-renderer_amd/csrc "$@" \
   -Rpass-analysis=kernel-resource-usage $R/rt-gaussian-splat-renderer_amd/csrc/rtgs_trace.hip -o /dev/null 2>&1 |
 python3 -c '
 import re, sys

@@ -13,7 +13,7 @@ for c in ${CFGS:-c3 c5 c3sh}; do
 done
 fi
 [[ " $PARTS " == *" rest "* ]] || exit 0
-hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared -I$R/include -I$R/rt-gaussian-splat-renderer_amd/csrc -DRTGS_STAMPS=1 \
+hipcc -O3 -fno-slp-vectorize --offload-arch=gfx950 -std=c++17 -fPIC -shared -I$R/include -I$R/rt-gaussian-splat-renderer_amd/csrc -DRTGS_STAMPS=1 \
   $R/rt-gaussian-splat-renderer_amd/csrc/rtgs_trace.hip $R/rt-gaussian-splat-renderer_amd/csrc/rtgs_ops.hip -o $R/gpurun_out/lib_stamps.so 2>/dev/null
 {
   echo "# k_trace per-phase s_memtime stamps (diagnostic -DRTGS_STAMPS=1 build, wave 0 of every workgroup), MI355X, round $RND"
