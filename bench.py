@@ -48,9 +48,12 @@ MIN_TIMED_S = 0.25          # a timed batch shorter than this is repeated and th
 MAX_BATCHES = 400
 LDS_BYTES_PER_INST = 256    # 64 lanes x 4 B: k_trace's LDS instructions are b32 (upper bound for its few b128 reads: x4)
 N_CU = 256
-# vector L1 (TCP): one 64-B tag access per clock per CU (MI355X_MICROARCH.md: 64 B/clk/CU) -- what the per-lane SH gathers
-# of the SH instantiations run into (TCP_TOTAL_CACHE_ACCESSES_sum, profiles/r04_c3sh_summary.json: 0.94 of this)
-L1_PEAK_GBS = N_CU * 64 * ENGINE_CLOCK_HZ / 1e9
+# vector L1 (TCP): what the per-lane SH gathers of the gathering SH forms run into.  Measured ceiling
+# (tools/ubench/l1_tag_rate.hip, profiles/r04_ubench_l1_tag_rate.txt): TCP_TOTAL_CACHE_ACCESSES_sum advances 0.97-1.00 per
+# clock per CU for uniform 16-B-per-lane gathers of an L1-resident table (16 per instruction at least: one per 4 lanes) and
+# 1.25 for the SH-like pattern (~6 records per 16 lanes, same offset) with the TA 99 % busy; an access moves up to 64 B.
+L1_PEAK_ACCESSES_PER_CLK = 1.25
+L1_PEAK_GBS = N_CU * 64 * L1_PEAK_ACCESSES_PER_CLK * ENGINE_CLOCK_HZ / 1e9
 LDS_PEAK_GBS = N_CU * 128 * ENGINE_CLOCK_HZ / 1e9
 
 
@@ -597,8 +600,9 @@ def rank_main(args) -> int:
                          "counts": counts, "useful_lane_share": lanes,
                          "lds_bytes_per_s": lds_bps, "lds_insts_per_launch": pc["lds"],
                          "note": "bound = the resource with the highest fraction of its peak among fractions{}: valu = "
-                                 "SQ_INSTS_VALU / (1024 SIMDs x 2.4 GHz / 2); vmem-L1 = TCP_TOTAL_CACHE_ACCESSES_sum x 64 B / "
-                                 "(256 CUs x 64 B/clk x 2.4 GHz); lds = SQ_LDS_IDX_ACTIVE / (GRBM_GUI_ACTIVE x 256 CUs), rocprofv3's LdsUtil, of the profiled run "
+                                 "SQ_INSTS_VALU / (1024 SIMDs x 2.4 GHz / 2); vmem-L1 = TCP_TOTAL_CACHE_ACCESSES_sum / "
+                                 "(256 CUs x 1.25 accesses/clk x 2.4 GHz), the rate a pure SH-like gather loop reaches "
+                                 "(profiles/r04_ubench_l1_tag_rate.txt; x 64 B for the GB/s figures); lds = SQ_LDS_IDX_ACTIVE / (GRBM_GUI_ACTIVE x 256 CUs), rocprofv3's LdsUtil, of the profiled run "
                                  "(without that pass: SQ_INSTS_LDS x 256 B / (256 CUs x 128 B/clk x 2.4 GHz)); "
                                  "hbm = (FETCH_SIZE x 2 + WRITE_SIZE) / 8 TB/s; all null when the "
                                  "committed counters are of another source hash.  speedup_vs_streamed_model = "
