@@ -24,6 +24,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -77,6 +78,9 @@ def parse(argv=None):
                     "the three of them); or explicit per-rank shares, e.g. 0.7,0.3")
     ap.add_argument("--dist-timeout", type=float, default=300.0, help="seconds: rendezvous and every collective "
                     "(init_process_group timeout)")
+    ap.add_argument("--mode-timeout", type=float, default=0.0, help="N > 1, seconds a tile deal after the first gets before "
+                    "the ranks give it up and rank 0 reports the best verified deal so far (0: four times what the "
+                    "first deal took, at least 120 s)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds the self-spawned ranks get "
                     "before the launcher ends them and exits 124")
     return ap.parse_args(argv)
@@ -470,49 +474,10 @@ def rank_main(args) -> int:
                  "wedges": ["wedges"]}.get(args.partition)
         if modes is None:
             raise SystemExit("--partition: both | all | equal | auto | wedges | s0,s1,...")
-    runs = {}
-    for mode in modes:
-        try:
-            runs[mode] = run_mode(mode)
-        except Exception as exc:                       # (a deal that cannot run must not take the other one's number with it)
-            if mode == modes[0] and len(modes) == 1:
-                raise
-            print(f"bench.py rank {rank}: partition {mode!r} failed: {exc!r}", file=sys.stderr)
-            runs[mode] = None
-    choice = [None]
-    if rank == 0:
-        ok = {m: r for m, r in runs.items() if r is not None and (world == 1 or r["verified"])}
-        pool = ok or {m: r for m, r in runs.items() if r is not None}
-        choice = [min(pool, key=lambda m: pool[m]["elapsed"]) if pool else None]
-    if world > 1:
-        dist.broadcast_object_list(choice, src=0)
-    if choice[0] is None or runs.get(choice[0]) is None:
-        raise SystemExit("bench.py: no tile deal ran to completion")
-    best = runs[choice[0]]
-    renderer, batches, elapsed = best["renderer"], best["batches"], best["elapsed"]
-    trace_ms, project_ms, per_rank, verified = best["trace_ms"], best["project_ms"], best["per_rank"], best["verified"]
-
-    # SURVEY 8(d) secondary figures: per-frame HIP-event times (median of 30 frames, first launch
-    # to framebuffer complete) and closest-hit queries/s = depth x rays/s
-    frame_ms_median = None
-    if world == 1:
-        # first launch to framebuffer complete, one frame at a time (whole frames are never overlapped on one
-        # GPU: two frames in flight on two streams measured 0.1468 -> 0.1733 ms per frame at c3, 1.339 -> 1.369 at c5)
-        one = TileParallelRenderer(scene, camera, depth=cfg.depth, rank=0, world=1)
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(30)]
-        for _ in range(3):
-            one.render_frame()
-        torch.cuda.synchronize()
-        for a_, b_ in evs:
-            a_.record()
-            one.render_frame()
-            b_.record()
-        one.finish()
-        torch.cuda.synchronize()
-        frame_ms_median = sorted(a_.elapsed_time(b_) for a_, b_ in evs)[len(evs) // 2]
-        one.close()
-
-    if rank == 0:
+    def emit_line(best, reported, abandoned=None, frame_ms_median=None):
+        """Rank 0: the ONE JSON line, from a finished run of a tile deal (`best` = a run_mode result)."""
+        renderer, batches, elapsed = best["renderer"], best["batches"], best["elapsed"]
+        trace_ms, project_ms, per_rank, verified = best["trace_ms"], best["project_ms"], best["per_rank"], best["verified"]
         ms = elapsed / args.steps * 1e3
         mrays = cfg.rays / (elapsed / args.steps) / 1e6
         bpr = synthetic.bytes_per_ray(cfg.n, cfg.sh, cfg.depth)
@@ -642,10 +607,89 @@ def rank_main(args) -> int:
                                             "deal": r["partition"], "shares": r["shares"], "calibration": r["calibration"],
                                             "per_rank_trace_ms": r["per_rank"]["trace_ms"]})
                 for m, r in runs.items()}
-            line["secondary"]["partition_reported"] = str(choice[0])
+            line["secondary"]["partition_reported"] = str(reported)
+            if abandoned is not None:
+                line["secondary"]["partition_abandoned"] = abandoned
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, arrays, cam, args.cpu_rays)
         print(json.dumps(line), flush=True)
+
+    runs = {}
+    emit = [emit_line]     # (what the watchdog below prints with)
+    t_first = None
+    for mode in modes:
+        # A deal after the first must not take the first one's number with it -- neither by raising nor by HANGING (the
+        # point-to-point exchange of the unequal deals has never met RCCL: ADVICE r3): every rank arms the same
+        # watchdog; when it fires, rank 0 prints the line of the best verified deal so far and every rank leaves.
+        watchdog = None
+        if world > 1 and t_first is not None and any(r is not None for r in runs.values()):
+            budget = args.mode_timeout if args.mode_timeout > 0 else max(120.0, 4.0 * t_first)
+
+            def give_up(mode=mode, budget=budget):
+                print(f"bench.py rank {rank}: partition {mode!r} made no end in {budget:.0f} s: given up", file=sys.stderr, flush=True)
+                if rank != 0:
+                    time.sleep(5.0)          # (rank 0 prints first)
+                    os._exit(0)
+                good = {m: r for m, r in runs.items() if r is not None and r["verified"]}
+                if not good or emit[0] is None:
+                    os._exit(EXIT_TIMEOUT)
+                m = min(good, key=lambda m: good[m]["elapsed"])
+                emit[0](good[m], m, abandoned={"partition": str(mode), "after_s": budget})
+                os._exit(0)
+
+            watchdog = threading.Timer(budget, give_up)
+            watchdog.daemon = True
+            watchdog.start()
+        t0 = time.perf_counter()
+        try:
+            if os.environ.get("RTGS_BENCH_TEST_HANG") == str(mode) and rank == world - 1:
+                time.sleep(1e6)                        # (test hook: this deal never finishes on the last rank)
+            runs[mode] = run_mode(mode)
+        except Exception as exc:                       # (a deal that cannot run must not take the other one's number with it)
+            if mode == modes[0] and len(modes) == 1:
+                raise
+            print(f"bench.py rank {rank}: partition {mode!r} failed: {exc!r}", file=sys.stderr)
+            runs[mode] = None
+        finally:
+            if watchdog is not None:
+                watchdog.cancel()
+        if t_first is None:
+            t_first = time.perf_counter() - t0
+    choice = [None]
+    if rank == 0:
+        ok = {m: r for m, r in runs.items() if r is not None and (world == 1 or r["verified"])}
+        pool = ok or {m: r for m, r in runs.items() if r is not None}
+        choice = [min(pool, key=lambda m: pool[m]["elapsed"]) if pool else None]
+    if world > 1:
+        dist.broadcast_object_list(choice, src=0)
+    if choice[0] is None or runs.get(choice[0]) is None:
+        raise SystemExit("bench.py: no tile deal ran to completion")
+    best = runs[choice[0]]
+    renderer, batches, elapsed = best["renderer"], best["batches"], best["elapsed"]
+    trace_ms, project_ms, per_rank, verified = best["trace_ms"], best["project_ms"], best["per_rank"], best["verified"]
+
+    # SURVEY 8(d) secondary figures: per-frame HIP-event times (median of 30 frames, first launch
+    # to framebuffer complete) and closest-hit queries/s = depth x rays/s
+    frame_ms_median = None
+    if world == 1:
+        # first launch to framebuffer complete, one frame at a time (whole frames are never overlapped on one
+        # GPU: two frames in flight on two streams measured 0.1468 -> 0.1733 ms per frame at c3, 1.339 -> 1.369 at c5)
+        one = TileParallelRenderer(scene, camera, depth=cfg.depth, rank=0, world=1)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(30)]
+        for _ in range(3):
+            one.render_frame()
+        torch.cuda.synchronize()
+        for a_, b_ in evs:
+            a_.record()
+            one.render_frame()
+            b_.record()
+        one.finish()
+        torch.cuda.synchronize()
+        frame_ms_median = sorted(a_.elapsed_time(b_) for a_, b_ in evs)[len(evs) // 2]
+        one.close()
+
+    if rank == 0:
+        emit_line(best, choice[0], frame_ms_median=frame_ms_median)
     status = 0
     if world > 1:
         # every rank leaves with the same status: an unverified run must not look like a measurement

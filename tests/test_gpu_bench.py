@@ -66,6 +66,21 @@ def test_the_sector_deal_with_its_region_cull_verifies_through_the_real_exchange
     assert line["per_rank"]["local_tiles"] == [950, 950]
 
 
+def test_a_deal_that_hangs_does_not_take_the_finished_deals_number_with_it():
+    # the unequal deals' point-to-point exchange has never met RCCL: if the second deal never ends (test hook: the last
+    # rank sleeps instead of running it), every rank's watchdog fires, rank 0 prints the line of the deal that did
+    # finish and verify, and the job ends with status 0 -- in the torchrun form too, where no launcher of ours watches
+    out, line = _run(["--gpus", "2", "--backend", "gloo", "--same-device", "--steps", "4", "--warmup", "1",
+                      "--config", "c2", "--mode-timeout", "20"], {"RTGS_BENCH_TEST_HANG": "auto"}, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert len([l for l in out.stdout.splitlines() if l.startswith("{")]) == 1
+    assert line["verified"] is True and line["n_gpus"] == 2
+    sec = line["secondary"]
+    assert sec["partition_reported"] == "equal" and sec["partition_abandoned"]["partition"] == "auto"
+    assert sec["partitions"]["equal"]["verified"] is True and "auto" not in sec["partitions"]
+    assert "given up" in out.stderr
+
+
 def test_launched_by_torch_distributed_run_it_is_a_rank_as_before():
     # the driver's other launch form: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...
     import socket
