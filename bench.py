@@ -655,6 +655,12 @@ def rank_main(args) -> int:
                 watchdog.cancel()
         if t_first is None:
             t_first = time.perf_counter() - t0
+        if world > 1 and rank == 0 and runs[mode] is not None and len(modes) > 1:
+            # a record on STDERR in case a later deal takes the job down (stdout carries exactly one line, at the end)
+            r = runs[mode]
+            print(f"bench.py: partition {mode!r} done: {cfg.rays / (r['elapsed'] / args.steps) / 1e6:.1f} Mrays/s, "
+                  f"{r['elapsed'] / args.steps * 1e3:.4f} ms/frame, verified {r['verified']}, deal {r['partition']}",
+                  file=sys.stderr, flush=True)
     choice = [None]
     if rank == 0:
         ok = {m: r for m, r in runs.items() if r is not None and (world == 1 or r["verified"])}
