@@ -55,8 +55,43 @@ def c_render_checked(name, extra, n_check):
     save(name + "_crop", pix, r)
 
 
+def tile_pixels(width, height, edge, seed):
+    """One seeded pixel inside every edge x edge tile of the frame (tiles anchored at (0, 0), the kernels' grid;
+    a tile cut by the frame's border draws from the part inside), tile-row major."""
+    tx, ty = (width + edge - 1) // edge, (height + edge - 1) // edge
+    rng = np.random.default_rng(seed)
+    ti, tj = np.meshgrid(np.arange(tx), np.arange(ty), indexing="ij")
+    ti, tj = ti.ravel(), tj.ravel()
+    wi = np.minimum(edge, width - ti * edge)
+    hj = np.minimum(edge, height - tj * edge)
+    i = ti * edge + (rng.random(ti.size) * wi).astype(np.int64)
+    j = tj * edge + (rng.random(tj.size) * hj).astype(np.int64)
+    return np.stack([i, j], axis=-1).astype(np.int32)
+
+
+def c_render_tiles(name, edge, seed, n_check):
+    """a golden pixel in EVERY tile of the headline frames -- the unit at which the kernel can fail
+    locally (a bin overflow, a macro-tile list cut short).  C oracle, `n_check` pixels cross-checked against NumPy."""
+    arrays, cam, depth = scenes.config_case(name)
+    pix = tile_pixels(cam["width"], cam["height"], edge, seed)
+    r = c_oracle.render(arrays, cam, depth, pix)
+    sub = np.arange(0, pix.shape[0], pix.shape[0] // n_check)[:n_check]
+    chk = numpy_render(arrays, cam, depth, pix[sub])
+    assert np.abs(chk["sample"] - r["sample"][sub]).max() < 1e-9
+    assert (chk["hits"] == r["hits"][sub]).all()
+    save(name + "_tiles", pix, r)
+
+
 def main():
     only = set(sys.argv[1:])
+    if only and only <= {"c3_tiles", "c5_tiles"}:
+        # c3: one pixel per 8x8 WAVE tile (240 x 135 = 32 400 pixels, ~1.5 min on 8 cores);
+        # c5: one per 16x16 macro-tile of the 4K frame (32 400 pixels x 1 M Gaussians + SH: ~10 min)
+        if "c3_tiles" in only:
+            c_render_tiles("c3", 8, 3308, 256)
+        if "c5_tiles" in only:
+            c_render_tiles("c5", 16, 5516, 64)
+        return
     if only == {"c5"}:
         # c5: 1 M Gaussians + degree-3 SH at 3840x2160 (gaussian.py:140-181, 183-201): 64x36 centre
         # crop + 1024 random pixels, C oracle (~1 min on 8 cores), 64 pixels cross-checked
@@ -73,6 +108,8 @@ def main():
     # c3: same pixel pattern, C oracle, cross-checked against NumPy on a subset
     c_render_checked("c3", 4096, 192)
     c_render_checked("c5", 1024, 64)
+    c_render_tiles("c3", 8, 3308, 256)
+    c_render_tiles("c5", 16, 5516, 64)
     # special cases, full frames
     for name, fn in scenes.CASES.items():
         arrays, cam, depth = fn()

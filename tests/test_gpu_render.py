@@ -25,8 +25,11 @@ def render_full(name):
     return tracer, cam, depth
 
 
+# c3_tiles / c5_tiles (round 5): one golden pixel in EVERY 8x8 wave tile of the c3 frame and in every
+# 16x16 macro-tile of the c5 frame -- the units at which the kernel can fail locally (a bin overflow, a tile list cut
+# short) -- where the crops cover 0.3 % of the pixels and at most 12 % of the tiles
 @pytest.mark.parametrize("name", ["c1_full", "c2_crop", "c3_crop", "c5_crop", "oblique_full", "inside_full",
-                                  "sh_full", "shallow_full"])
+                                  "sh_full", "shallow_full", "c3_tiles", "c5_tiles"])
 def test_golden_parity(name):
     g = U.golden(name)
     tracer, cam, depth = render_full(name.split("_")[0])
@@ -47,7 +50,7 @@ def test_golden_parity(name):
 
 
 @pytest.mark.parametrize("name", ["c1_full", "c2_crop", "c3_crop", "c5_crop", "oblique_full", "inside_full",
-                                  "sh_full", "shallow_full"])
+                                  "sh_full", "shallow_full", "c3_tiles", "c5_tiles"])
 def test_fragile_pixels_stay_plausible(name):
     # a fragile pixel may take the other branch of a discontinuity, never produce garbage:
     # it must still be within one contribution (alpha <= opacity_max = 0.9) of the golden

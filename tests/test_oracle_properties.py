@@ -199,3 +199,21 @@ def test_c3_golden_sample_is_reproduced_by_the_c_oracle():
     c = c_oracle.render(arrays, cam, depth, g["pixels"][sel])
     assert np.array_equal(c["sample"], g["sample"][sel])
     assert (c["hits"] == g["hits"][sel]).all()
+
+
+@pytest.mark.parametrize("name,edge,stride", [("c3_tiles", 8, 64), ("c5_tiles", 16, 700)])
+def test_tile_goldens_own_one_pixel_in_every_tile_and_are_reproduced(name, edge, stride):
+    # round 5: the fixture names exactly one pixel inside EVERY edge x edge tile of the headline frame
+    # (8x8 wave tiles at c3, 16x16 macro-tiles at c5), and a strided subset is reproduced by the C oracle bit for bit
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    arrays, cam, depth = scenes.config_case(name.split("_")[0])
+    pix = g["pixels"]
+    tx, ty = (cam["width"] + edge - 1) // edge, (cam["height"] + edge - 1) // edge
+    assert pix.shape == (tx * ty, 2) and (pix[:, 0] < cam["width"]).all() and (pix[:, 1] < cam["height"]).all()
+    owner = (pix[:, 0] // edge) * ty + pix[:, 1] // edge
+    assert np.array_equal(np.sort(owner), np.arange(tx * ty))            # every tile exactly once
+    assert g["fragile"].mean() < 5e-3 and g["hits"].mean() > 5
+    sel = np.arange(0, pix.shape[0], stride)
+    c = c_oracle.render(arrays, cam, depth, pix[sel])
+    assert np.array_equal(c["sample"], g["sample"][sel])
+    assert (c["hits"] == g["hits"][sel]).all() and (c["fragile"] == g["fragile"][sel]).all()
