@@ -44,9 +44,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X spec peak, /opt/skills/guides/MI355X_MICROARCH.m
 N_SIMD = 1024
 ENGINE_CLOCK_HZ = 2.4e9
 VALU_PEAK_GINST = N_SIMD * ENGINE_CLOCK_HZ / 2 / 1e9   # G wave-instructions / s
-PROFILE_ROUND = "r04"
-MIN_TIMED_S = 0.25          # a timed batch shorter than this is repeated and the MEDIAN batch is reported
-MAX_BATCHES = 400
+PROFILE_ROUND = "r05"
+MIN_TIMED_S = 1.0           # a timed batch shorter than this is repeated and the MEDIAN batch is reported
+MAX_BATCHES = 1600
 LDS_BYTES_PER_INST = 256    # 64 lanes x 4 B: k_trace's LDS instructions are b32 (upper bound for its few b128 reads: x4)
 N_CU = 256
 # vector L1 (TCP): what the per-lane SH gathers of the gathering SH forms run into.  Measured ceiling
@@ -76,6 +76,11 @@ def parse(argv=None):
                     "(shares calibrated on this machine, point to point), both = time both and report the faster "
                     "verified one; wedges = one compact image sector per rank, its projection culled to it (all = "
                     "the three of them); or explicit per-rank shares, e.g. 0.7,0.3")
+    ap.add_argument("--landing", default="both", help="N > 1: where frames land -- root (every frame on rank 0, one gather "
+                    "per batch), rotate (frame f on rank f mod N, one all_to_all per batch of frames), both = time both")
+    ap.add_argument("--gather-batch", type=int, default=0, help="N > 1: frames per library call and collective for the "
+                    "batched deals (0: 8, rounded up to a multiple of N for rotating roots); the root deal is ALSO timed "
+                    "frame by frame (batch 1, round 4's loop)")
     ap.add_argument("--dist-timeout", type=float, default=300.0, help="seconds: rendezvous and every collective "
                     "(init_process_group timeout)")
     ap.add_argument("--mode-timeout", type=float, default=0.0, help="N > 1, seconds a tile deal after the first gets before "
@@ -154,36 +159,40 @@ def spawn_ranks(world: int, argv, script=None, python=None, timeout: float = 150
         raise
 
 
+CPU_SUBSET = 4096      # "a fixed 4 096-ray random pixel subset (seeded)"
+
+
 def cpu_baseline(cfg, arrays, cam, n_rays):
-    """The oracle (NumPy, fp32, the reference's literal loop: `depth` closest-hit peels) timed
-    on this host, on a seeded pixel subset of the same workload.  Reported only."""
+    """The oracle timed on this host, on SURVEY 8(d)'s seeded 4 096-pixel subset of the same frame: the C / OpenMP
+    restatement (fp64, the closest-hit + midpoint evaluation of the reference, all cores) on all 4 096 pixels, and the
+    NumPy restatement (fp32, the reference's literal loop: `depth` closest-hit peels, one core) on the first `n_rays`
+    of them -- the NumPy loop does ~16 rays/s at c3, 4 096 rays would be four minutes of the 10-30 s of CPU work the
+    bench contract allows.  Reported only."""
     from oracle import rtgs_ref as ref
 
     rng = np.random.default_rng(4242)
-    pix = np.stack([rng.integers(0, cfg.width, n_rays), rng.integers(0, cfg.height, n_rays)], axis=-1)
+    subset = np.stack([rng.integers(0, cfg.width, CPU_SUBSET), rng.integers(0, cfg.height, CPU_SUBSET)], axis=-1)
+    pix = subset[:n_rays]
     osc = ref.OracleScene(**arrays, dtype=np.float32)
     t0 = time.perf_counter()
     ref.render_peel(osc, cam["position"], cam["rotation"], cfg.width, cfg.height, cam["fx"],
                     cam["fy"], depth=cfg.depth, pixels=pix)
     dt = time.perf_counter() - t0
     out = {"value": n_rays / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
-           "sample": f"{n_rays} seeded random pixels of the {cfg.name} frame, NumPy fp32 literal "
-                     f"depth-{cfg.depth} peel loop, {dt:.1f} s, 1 of {os.cpu_count()} cores "
-                     "(subset extrapolation)",
-           "deviation": f"SURVEY 8(d) fixes a 4096-ray subset; {n_rays} rays keep this leg inside the "
-                        "10-30 s of CPU work the bench contract allows (the NumPy loop does ~16 rays/s at c3)"}
-    # optional second line: the C/OpenMP restatement on all cores
+           "sample": f"the first {n_rays} of SURVEY 8(d)'s {CPU_SUBSET} seeded random pixels of the {cfg.name} frame, NumPy "
+                     f"fp32 literal depth-{cfg.depth} peel loop, {dt:.1f} s, 1 of {os.cpu_count()} cores "
+                     "(subset extrapolation); the whole subset is timed through the C restatement: c_openmp"}
+    # second line: the C/OpenMP restatement on all cores, the WHOLE 4 096-pixel subset
     try:
         from oracle import c_oracle
         if c_oracle.available():
-            n2 = min(cfg.rays, 16384)
-            pix2 = np.stack([rng.integers(0, cfg.width, n2), rng.integers(0, cfg.height, n2)], axis=-1)
             t0 = time.perf_counter()
-            c_oracle.render(arrays, cam, cfg.depth, pix2)
+            c_oracle.render(arrays, cam, cfg.depth, subset)
             dt2 = time.perf_counter() - t0
-            out["c_openmp"] = {"value": n2 / dt2 / 1e6, "unit": "Mrays/s",
+            out["c_openmp"] = {"value": CPU_SUBSET / dt2 / 1e6, "unit": "Mrays/s", "kind": "port",
                                "cores": len(os.sched_getaffinity(0)),
-                               "sample": f"{n2} seeded random pixels, C fp64 one-pass, {dt2:.1f} s"}
+                               "sample": f"all {CPU_SUBSET} pixels of SURVEY 8(d)'s seeded subset, C fp64 one-pass "
+                                         f"(oracle/rtgs_oracle.c, OpenMP), {dt2:.1f} s"}
     except Exception as exc:  # the optional line must never break the bench
         out["c_openmp"] = {"error": repr(exc)}
     return out
@@ -214,14 +223,31 @@ def closest_hit_rates(scene, cam):
     return out
 
 
-def raytracer_api_times(rtgs, scene, camera, cfg):
-    """ms per whole sample through the drop-in class: sample_all(depth), and the viewer's pattern of
-    `depth` sample(depth) calls (one peel per call)."""
+def raytracer_api_times(rtgs, scene, camera, cfg, prefix=""):
+    """ms per whole sample through the drop-in class: sample_all(depth); the viewer's pattern of `depth`
+    sample(depth) calls (one peel per call) with a STILL camera (the peel lists of the pose are kept: 16 streaming
+    peels, no traversal); and the same with a MOVING camera -- a new pose per sample, as the reference's viewer resets
+    its sample on every camera event (__main__.py:214-216, 228-230, 248-250: clear_sample(), num_steps = 0), then
+    `depth` x sample(depth) (__main__.py:253-256): every sample pays the traversal and the lists again."""
+    from rtgs.utils.types import vec3
     tracer = rtgs.RayTracer((cfg.width, cfg.height), scene, camera)
+    home = tuple(float(v) for v in camera.position)
+    turn = [0]
+
+    def moving_camera_sample():
+        turn[0] += 1
+        a = 0.05 * turn[0]
+        camera.position = vec3((home[0] + 0.2 * float(np.sin(a)), home[1] + 0.1 * float(np.cos(a)), home[2]))
+        tracer.clear_sample()
+        tracer.num_steps = 0
+        for _ in range(cfg.depth):
+            tracer.sample(cfg.depth)
+
     out = {}
-    for name, reps, fn in (("raytracer_sample_all_ms", 50, lambda: tracer.sample_all(cfg.depth)),
-                           (f"raytracer_sample_x{cfg.depth}_ms", 5,
-                            lambda: [tracer.sample(cfg.depth) for _ in range(cfg.depth)])):
+    for name, reps, fn in ((prefix + "raytracer_sample_all_ms", 50, lambda: tracer.sample_all(cfg.depth)),
+                           (prefix + f"raytracer_sample_x{cfg.depth}_ms", 5,
+                            lambda: [tracer.sample(cfg.depth) for _ in range(cfg.depth)]),
+                           (prefix + f"raytracer_sample_x{cfg.depth}_new_pose_ms", 10, moving_camera_sample)):
         for _ in range(2):
             fn()
         torch.cuda.synchronize()
@@ -230,6 +256,7 @@ def raytracer_api_times(rtgs, scene, camera, cfg):
             fn()
         torch.cuda.synchronize()
         out[name] = (time.perf_counter() - t0) / reps * 1e3
+    camera.position = vec3(home)
     return out
 
 
@@ -361,21 +388,33 @@ def rank_main(args) -> int:
 
     def verify(renderer):
         """N > 1: consecutive frames with DIFFERENT camera poses are queued back to back through the pipeline (no
-        host synchronisation in between); what is left in the framebuffer must equal the single-rank render of the
-        LAST pose bit for bit -- for both orders of the two poses and for an odd number of frames, so that each
-        half of the ring ends a sequence (a stale or swapped half would show the other pose)."""
+        host synchronisation in between); every frame that is held by a rank afterwards -- rank 0's framebuffer for
+        the single root, every rank's landed frames of the last batch for rotating roots -- must equal the
+        single-rank render of THAT frame's pose bit for bit.  Three sequences: two poses in both orders and an odd
+        count (each half of a ring ends a sequence; a stale or swapped buffer shows the other pose), then one that
+        ends in a partial batch.  The outcome is all-reduced: every rank returns the same verdict."""
         pose_a, pose_b = (0.15, -0.1, 3.0), tuple(cam["position"])
-        sequences = [(pose_a, pose_b), (pose_b, pose_a), (pose_b, pose_a, pose_b)]
-        finals, ok = [], None
+        rot = tuple(cam["rotation"])
+        B = renderer.gather_batch
+        sequences = [(pose_a, pose_b), (pose_b, pose_a), (pose_b, pose_a, pose_b),
+                     tuple((pose_a, pose_b)[i % 2] for i in range(B + 3)), tuple((pose_b, pose_a)[i % 3 == 0] for i in range(2 * B))]
+        held = []                                          # (pose, clone of the landed image)
         for seq in sequences:
-            for p in seq:
-                camera.position = vec3(p)
-                renderer.render_frame()
+            first = renderer._frame
+            renderer.render_frames([(p, rot) for p in seq])
             renderer.finish()
             torch.cuda.synchronize()
-            if rank == 0:
-                finals.append(renderer.framebuffer.clone())
-        if rank == 0:
+            if renderer.landing == "rotate":
+                last0 = first + (len(seq) - 1) // B * B    # the last batch of the sequence, complete or partial
+                mine = [(f, img) for f, img in renderer.landed_frames() if last0 <= f < first + len(seq)]
+                want_n = len([f for f in range(last0, first + len(seq)) if f % world == rank])
+                if len(mine) != want_n:
+                    held.append((None, None))
+                held += [(seq[f - first], img.clone()) for f, img in mine]
+            elif rank == 0:
+                held.append((seq[-1], renderer.framebuffer.clone()))
+        ok = True
+        if held:
             single = TileParallelRenderer(scene, camera, depth=cfg.depth, rank=0, world=1)
             want = {}
             for p in (pose_a, pose_b):
@@ -385,20 +424,24 @@ def rank_main(args) -> int:
                 torch.cuda.synchronize()
                 want[p] = single.framebuffer.clone()
             ok = not torch.equal(want[pose_a], want[pose_b])
-            for seq, got in zip(sequences, finals):
-                ok = ok and bool(torch.equal(want[seq[-1]], got))
+            for p, got in held:
+                ok = ok and p is not None and bool(torch.equal(want[p], got))
         camera.position = vec3(cam["position"])
-        return ok
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item())
 
-    def run_mode(partition):
-        """One tile deal end to end: construct (\"auto\" calibrates), warm up, the timed batches, the dominant
-        kernel alone, every rank's shard times, the verification.  Collective: every rank runs the same modes."""
+    def run_mode(mode):
+        """One deal -- (partition, landing, frames per call and collective) -- end to end: construct (\"auto\"
+        calibrates), warm up, the timed batches, the dominant kernel alone, every rank's shard times, the
+        verification.  Collective: every rank runs the same modes."""
         from rtgs.parallel import _phase
-        _phase("bench: mode", partition)
-        renderer = TileParallelRenderer(scene, camera, depth=cfg.depth, rank=rank, world=world, partition=partition)
+        partition, landing, gbatch = mode
+        _phase("bench: mode", mode)
+        renderer = TileParallelRenderer(scene, camera, depth=cfg.depth, rank=rank, world=world, partition=partition,
+                                        landing=landing, gather_batch=gbatch if world > 1 else None)
         _phase("bench: warm-up")
-        for _ in range(args.warmup):
-            renderer.render_frame()
+        renderer.render_frames(count=args.warmup)
         renderer.finish()
         _phase("bench: timed batches")
 
@@ -406,8 +449,7 @@ def rank_main(args) -> int:
             """EXACTLY args.steps frames between barrier + synchronize on both sides; MAX over ranks."""
             sync()
             t0 = time.perf_counter()
-            for _ in range(args.steps):
-                renderer.render_frame()
+            renderer.render_frames(count=args.steps)     # (one library call and one collective per batch of the deal)
             renderer.finish()
             sync()
             dt = time.perf_counter() - t0
@@ -458,22 +500,36 @@ def rank_main(args) -> int:
         verified = verify(renderer) if world > 1 else None
         _phase("bench: mode done", verified)
         return dict(renderer=renderer, batches=batches, elapsed=elapsed, trace_ms=trace_ms, project_ms=project_ms,
-                    per_rank=per_rank, verified=verified, partition=renderer.partition.name,
+                    per_rank=per_rank, verified=verified, partition=renderer.partition.name, landing=renderer.landing,
+                    gather_batch=renderer.gather_batch, rendering_ranks=sum(1 for c in renderer.partition.counts if c),
                     shares=renderer.partition.shares(), calibration=renderer.calibration)
 
-    # N > 1: the equal round-robin deal (one dist.gather), then the link-aware deal calibrated on this machine
-    # (unequal shares, point to point); the line reports the faster of the VERIFIED ones, `secondary.partitions` both
+    # N > 1, one run: round 4's loop (equal deal, every frame on rank 0, one gather per frame), the link-aware deal
+    # calibrated on this machine (unequal shares, point to point), and round 5's two -- B frames per library call and
+    # collective, landing on rank 0 and on ROTATING roots (frame f on rank f mod N, one all_to_all per batch).  The
+    # line reports the fastest VERIFIED one, `secondary.partitions` all of them.
     if world == 1:
-        modes = ["equal"]
-    elif "," in args.partition:
-        modes = [tuple(float(v) for v in args.partition.split(","))]
-        if len(modes[0]) != world:
-            raise SystemExit(f"--partition names {len(modes[0])} shares for {world} ranks")
+        modes = [("equal", "root", None)]
     else:
-        modes = {"both": ["equal", "auto"], "all": ["equal", "auto", "wedges"], "equal": ["equal"], "auto": ["auto"],
-                 "wedges": ["wedges"]}.get(args.partition)
-        if modes is None:
-            raise SystemExit("--partition: both | all | equal | auto | wedges | s0,s1,...")
+        if "," in args.partition:
+            parts = [tuple(float(v) for v in args.partition.split(","))]
+            if len(parts[0]) != world:
+                raise SystemExit(f"--partition names {len(parts[0])} shares for {world} ranks")
+        else:
+            parts = {"both": ["equal", "auto"], "all": ["equal", "auto", "wedges"], "equal": ["equal"], "auto": ["auto"],
+                     "wedges": ["wedges"]}.get(args.partition)
+            if parts is None:
+                raise SystemExit("--partition: both | all | equal | auto | wedges | s0,s1,...")
+        landings = {"both": ["root", "rotate"], "root": ["root"], "rotate": ["rotate"]}.get(args.landing)
+        if landings is None:
+            raise SystemExit("--landing: both | root | rotate")
+        gb = args.gather_batch if args.gather_batch > 0 else 8
+        modes = []
+        if "root" in landings:
+            modes += [(p_, "root", 1) for p_ in parts]
+            modes += [(p_, "root", gb) for p_ in parts if p_ != "auto" and gb > 1]
+        if "rotate" in landings:      # (rotating roots: every rank is a destination as often as any other -- no "auto")
+            modes += [(p_, "rotate", gb) for p_ in parts if p_ != "auto"]
     def emit_line(best, reported, abandoned=None, frame_ms_median=None):
         """Rank 0: the ONE JSON line, from a finished run of a tile deal (`best` = a run_mode result)."""
         renderer, batches, elapsed = best["renderer"], best["batches"], best["elapsed"]
@@ -523,9 +579,12 @@ def rank_main(args) -> int:
             f"Mrays/s at {cfg.width}x{cfg.height}, {cfg.n} Gaussians; achieved HBM GB/s vs peak"
         comm = ""
         if world > 1:
-            comm = " + RCCL gather" if args.backend == "nccl" else f" + {args.backend} gather (rehearsal, not RCCL)"
-            comm += f", {renderer.frames_in_flight} frames in flight per rank, {renderer.gather_batch} per gather"
-            comm += f", tile deal: {best['partition']}"
+            what = "all_to_all to rotating roots (frame f lands on rank f mod N)" if best["landing"] == "rotate" else "gather to rank 0"
+            comm = f" + RCCL {what}" if args.backend == "nccl" else f" + {args.backend} {what} (rehearsal, not RCCL)"
+            comm += (f", {renderer.frames_in_flight} frames in flight per rank, {renderer.gather_batch} frames per library "
+                     f"call and collective, tile deal: {best['partition']}")
+            if best["rendering_ranks"] < world:
+                comm += f" -- ONLY {best['rendering_ranks']} of {world} ranks render"
         line = {
             "metric": metric,
             "value": mrays, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
@@ -585,6 +644,15 @@ def rank_main(args) -> int:
             # the reference's own API path (ray_tracer.py:39-54, viewer loop __main__.py:253-256):
             # rtgs.RayTracer.sample_all (one call per sample) and sample() x depth (one peel per call)
             line["secondary"].update(raytracer_api_times(rtgs, scene, camera, cfg))
+            if cfg.name == "c3":
+                # the same three figures with degree-3 SH colours: the kernels every PLY capture takes (scene.py:106-107)
+                try:
+                    cfg_sh = synthetic.CONFIGS["c3sh"]
+                    scene_sh = rtgs.Scene.from_arrays(**synthetic.make_config_scene(cfg_sh))
+                    line["secondary"].update(raytracer_api_times(rtgs, scene_sh, camera, cfg_sh, prefix="c3sh_"))
+                    del scene_sh
+                except Exception as exc:      # a secondary figure must never break the headline
+                    line["secondary"]["c3sh_error"] = repr(exc)
             # the transmittance cut-off (extension, off in the headline: the reference has none)
             cut = TileParallelRenderer(scene, camera, depth=cfg.depth, rank=0, world=1, t_cutoff=5e-5)
             for _ in range(3):
@@ -603,9 +671,11 @@ def rank_main(args) -> int:
             line["per_rank"] = per_rank
         if world > 1:
             line["secondary"]["partitions"] = {
-                str(m): (None if r is None else {"ms_per_step": r["elapsed"] / args.steps * 1e3, "verified": r["verified"],
-                                            "deal": r["partition"], "shares": r["shares"], "calibration": r["calibration"],
-                                            "per_rank_trace_ms": r["per_rank"]["trace_ms"]})
+                str(m): (None if r is None else {"ms_per_step": r["elapsed"] / args.steps * 1e3,
+                                            "mrays_per_s": cfg.rays / (r["elapsed"] / args.steps) / 1e6, "verified": r["verified"],
+                                            "deal": r["partition"], "landing": r["landing"], "frames_per_collective": r["gather_batch"],
+                                            "rendering_ranks": r["rendering_ranks"], "shares": r["shares"],
+                                            "calibration": r["calibration"], "per_rank_trace_ms": r["per_rank"]["trace_ms"]})
                 for m, r in runs.items()}
             line["secondary"]["partition_reported"] = str(reported)
             if abandoned is not None:
@@ -614,61 +684,97 @@ def rank_main(args) -> int:
             line["cpu_baseline"] = cpu_baseline(cfg, arrays, cam, args.cpu_rays)
         print(json.dumps(line), flush=True)
 
+    def mode_name(m):
+        part, landing, gbatch = m
+        part = part if isinstance(part, str) else ",".join(f"{v:g}" for v in part)
+        return part if world == 1 else f"{part}/{landing}/B{gbatch}"
+
+    def pick(pool_of):
+        """The deal the line reports: the fastest VERIFIED one in which every rank renders (a calibrated deal that
+        leaves ranks empty is a single-GPU number under an N-GPU label: ADVICE r4 -- it stays under
+        secondary.partitions); failing that the fastest verified, failing that the fastest.  `elapsed`, `verified`
+        and the shares are all-reduced / identical on every rank, so every rank picks the same deal by itself."""
+        done = {m: r for m, r in pool_of.items() if r is not None}
+        for keep in (lambda r: (world == 1 or r["verified"]) and r["rendering_ranks"] == world,
+                     lambda r: world == 1 or r["verified"], lambda r: True):
+            pool = {m: r for m, r in done.items() if keep(r)}
+            if pool:
+                return min(pool, key=lambda m: pool[m]["elapsed"])
+        return None
+
     runs = {}
+    giving_up = threading.Event()      # set by a watchdog that has fired: the main thread then only waits for its os._exit
     emit = [emit_line]     # (what the watchdog below prints with)
     t_first = None
     for mode in modes:
-        # A deal after the first must not take the first one's number with it -- neither by raising nor by HANGING (the
-        # point-to-point exchange of the unequal deals has never met RCCL: ADVICE r3): every rank arms the same
-        # watchdog; when it fires, rank 0 prints the line of the best verified deal so far and every rank leaves.
+        name = mode_name(mode)
+        # A deal must not take an earlier one's number with it -- neither by raising nor by HANGING (the exchanges of
+        # the unequal and the rotating deals have never met RCCL): every rank arms the same watchdog; when it fires,
+        # rank 0 prints the line of the best verified deal so far and every rank leaves with the same status.  The
+        # watchdog stays armed through the deal's collective outcome below (ADVICE r4): a rank that RAISED is then in
+        # that all-reduce while its peers are still inside the deal's collectives, and it is the watchdog -- on every
+        # rank, the raiser included -- that ends the mismatch.
         watchdog = None
-        if world > 1 and t_first is not None and any(r is not None for r in runs.values()):
-            budget = args.mode_timeout if args.mode_timeout > 0 else max(120.0, 4.0 * t_first)
+        if world > 1:
+            budget = (args.mode_timeout if args.mode_timeout > 0 else
+                      max(120.0, 4.0 * t_first) if t_first is not None else max(600.0, args.dist_timeout))
 
-            def give_up(mode=mode, budget=budget):
-                print(f"bench.py rank {rank}: partition {mode!r} made no end in {budget:.0f} s: given up", file=sys.stderr, flush=True)
+            def give_up(name=name, budget=budget):
+                giving_up.set()
+                print(f"bench.py rank {rank}: deal {name!r} made no end in {budget:.0f} s: given up", file=sys.stderr, flush=True)
+                good = pick({m: r for m, r in runs.items() if r is not None and r["verified"]})
                 if rank != 0:
                     time.sleep(5.0)          # (rank 0 prints first)
-                    os._exit(0)
-                good = {m: r for m, r in runs.items() if r is not None and r["verified"]}
-                if not good or emit[0] is None:
+                    os._exit(0 if good is not None else EXIT_TIMEOUT)
+                if good is None or emit[0] is None:
                     os._exit(EXIT_TIMEOUT)
-                m = min(good, key=lambda m: good[m]["elapsed"])
-                emit[0](good[m], m, abandoned={"partition": str(mode), "after_s": budget})
+                emit[0](runs[good], good, abandoned={"partition": name, "after_s": budget})
                 os._exit(0)
 
             watchdog = threading.Timer(budget, give_up)
             watchdog.daemon = True
             watchdog.start()
         t0 = time.perf_counter()
+        res, err = None, None
         try:
-            if os.environ.get("RTGS_BENCH_TEST_HANG") == str(mode) and rank == world - 1:
-                time.sleep(1e6)                        # (test hook: this deal never finishes on the last rank)
-            runs[mode] = run_mode(mode)
-        except Exception as exc:                       # (a deal that cannot run must not take the other one's number with it)
-            if mode == modes[0] and len(modes) == 1:
-                raise
-            print(f"bench.py rank {rank}: partition {mode!r} failed: {exc!r}", file=sys.stderr)
-            runs[mode] = None
-        finally:
-            if watchdog is not None:
-                watchdog.cancel()
+            try:
+                if os.environ.get("RTGS_BENCH_TEST_HANG") == name and rank == world - 1:
+                    time.sleep(1e6)                    # (test hook: this deal never finishes on the last rank)
+                if os.environ.get("RTGS_BENCH_TEST_RAISE") == name and rank == world - 1:
+                    raise RuntimeError("test hook: this deal fails on the last rank")
+                res = run_mode(mode)
+            except Exception as exc:                   # (a deal that cannot run must not take the others' numbers with it)
+                err = exc
+                print(f"bench.py rank {rank}: deal {name!r} failed: {exc!r}", file=sys.stderr, flush=True)
+            if world > 1:
+                # the deal's outcome is COLLECTIVE: if any rank failed, every rank drops it
+                flag = torch.tensor([0 if res is None else 1], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 0:
+                    res = None
+        except BaseException:
+            # the watchdog is ending the job (a peer that has already left closes this rank's connections, which
+            # raises here): the watchdog thread owns the exit status and rank 0's line -- stay out of its way
+            while giving_up.is_set():
+                time.sleep(1.0)
+            raise
+        if giving_up.is_set():
+            while True:
+                time.sleep(1.0)
+        if watchdog is not None:
+            watchdog.cancel()
+        if res is None and len(modes) == 1:
+            raise err if err is not None else SystemExit(f"bench.py: deal {name!r} failed on another rank")
+        runs[name] = res
         if t_first is None:
             t_first = time.perf_counter() - t0
-        if world > 1 and rank == 0 and runs[mode] is not None and len(modes) > 1:
+        if world > 1 and rank == 0 and res is not None and len(modes) > 1:
             # a record on STDERR in case a later deal takes the job down (stdout carries exactly one line, at the end)
-            r = runs[mode]
-            print(f"bench.py: partition {mode!r} done: {cfg.rays / (r['elapsed'] / args.steps) / 1e6:.1f} Mrays/s, "
-                  f"{r['elapsed'] / args.steps * 1e3:.4f} ms/frame, verified {r['verified']}, deal {r['partition']}",
+            print(f"bench.py: deal {name!r} done: {cfg.rays / (res['elapsed'] / args.steps) / 1e6:.1f} Mrays/s, "
+                  f"{res['elapsed'] / args.steps * 1e3:.4f} ms/frame, verified {res['verified']}, tiles {res['partition']}",
                   file=sys.stderr, flush=True)
-    choice = [None]
-    if rank == 0:
-        ok = {m: r for m, r in runs.items() if r is not None and (world == 1 or r["verified"])}
-        pool = ok or {m: r for m, r in runs.items() if r is not None}
-        choice = [min(pool, key=lambda m: pool[m]["elapsed"]) if pool else None]
-    if world > 1:
-        dist.broadcast_object_list(choice, src=0)
-    if choice[0] is None or runs.get(choice[0]) is None:
+    choice = [pick(runs)]
+    if choice[0] is None:
         raise SystemExit("bench.py: no tile deal ran to completion")
     best = runs[choice[0]]
     renderer, batches, elapsed = best["renderer"], best["batches"], best["elapsed"]
@@ -699,9 +805,7 @@ def rank_main(args) -> int:
     status = 0
     if world > 1:
         # every rank leaves with the same status: an unverified run must not look like a measurement
-        flag = [verified if rank == 0 else None]
-        dist.broadcast_object_list(flag, src=0)
-        if flag[0] is not True:
+        if verified is not True:          # (all-reduced inside verify(): the same on every rank)
             print(f"bench.py rank {rank}: frames did not verify against the single-rank render", file=sys.stderr)
             status = EXIT_UNVERIFIED
         dist.destroy_process_group()

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RTGS_ABI_VERSION 6
+#define RTGS_ABI_VERSION 7
 #define RTGS_MAX_DEPTH 16        /* peels kept per ray in one pass (__main__.py:70 default) */
 #ifndef RTGS_TILE
 #define RTGS_TILE 16             /* macro-tile edge in pixels: one workgroup, the unit of sharding */
@@ -117,7 +117,7 @@ typedef struct RtgsTraceParams {
   float region[4];      /* with RTGS_TRACE_REGION (ABI v6): a rectangle of pixel-centre offsets from the image centre,
                            (X lo, Y lo, X hi, Y hi) with X = i + 0.5 - W/2, Y = j + 0.5 - H/2, that contains every pixel
                            of the shard -- one compact part of the frame per rank (rtgs.parallel.Partition.wedges).
-                           The per-frame projection of this call (projected = 0, rtgs_shard_frame, rtgs_frame_ahead)
+                           The per-frame projection of this call (projected = 0, rtgs_shard_frame, rtgs_shard_frames)
                            then treats Gaussians whose conservative screen bound misses it as culled: at 1 M
                            Gaussians an eighth-of-the-frame sector skips most of k_project's arithmetic and writes. */
 } RtgsTraceParams;
@@ -206,8 +206,7 @@ int rtgs_project(const RtgsScene* scene, const RtgsCamera* cam, void* workspace,
 
 /* rtgs_project exactly as rtgs_trace(projected = 0) would run it for the shard (tile_first,
  * tile_step): the supertile bins are only built when the shard is large enough for them to pay.
- * For callers that overlap frame f+1's projection (on a second stream, into a second workspace)
- * with frame f's trace, as rtgs.parallel.HipBackend.render does. */
+ * For callers that run a shard's projection apart from its trace (rtgs_trace with projected = 1). */
 int rtgs_project_shard(const RtgsScene* scene, const RtgsCamera* cam, int32_t tile_first,
                        int32_t tile_step, void* workspace, size_t workspace_bytes, rtgs_stream_t stream);
 
@@ -219,17 +218,19 @@ int rtgs_render(const RtgsScene* scene, const RtgsCamera* cam, int32_t depth, fl
                 int32_t tile_y0, int32_t tile_y1, float* sample_out, float* transmittance_out,
                 void* workspace, size_t workspace_bytes, rtgs_stream_t stream);
 
-/* ---- peel lists (ABI v6) ----
+/* ---- peel lists (ABI v6; v7: written at their real lengths) ----
  * The reference's viewer takes a sample as `depth` calls of RayTracer.sample (__main__.py:253-256), each
  * one peel (ray_tracer.py:39-54) that re-walks the scene for every pixel.  These three serve that call
  * pattern from ONE traversal: rtgs_trace_lists runs rtgs_trace's pass for the whole frame but, instead
- * of compositing, stores every ray's sorted DISTINCT entries (up to RTGS_MAX_DEPTH of them: Gaussian
- * index, exponent, t1) in `lists` (rtgs_peel_list_bytes(W, H) bytes, 16-B aligned, caller-owned;
- * 192 B per pixel); rtgs_peel composites entry k of every ray -- sample_buf += attenuation * alpha *
- * colour, attenuation *= 1 - alpha, exactly sample_step's update -- reading colours / opacities / SH
- * from the scene at call time; rtgs_peel_start writes the ray.start the first `peels_done` peels imply
- * (t1 of the last + 1e-8, +inf after a miss, 0 for none).  The lists depend on the Gaussians' geometry
- * and the camera only: they stay valid across samples while neither changes.
+ * of compositing, stores every ray's sorted DISTINCT entries (up to RTGS_MAX_DEPTH of them: a count per
+ * pixel, then Gaussian index, exponent and t1 per entry) in `lists` (rtgs_peel_list_bytes(W, H) bytes,
+ * 16-B aligned, caller-owned: 196 B per pixel of capacity, of which 4 B + 12 B per entry the pixel
+ * really has are written -- ABI v6 wrote a terminator into every unused slot); rtgs_peel composites
+ * entry k of every ray -- sample_buf += attenuation * alpha * colour, attenuation *= 1 - alpha, exactly
+ * sample_step's update -- reading colours / opacities / SH from the scene at call time; rtgs_peel_start
+ * writes the ray.start the first `peels_done` peels imply (t1 of the last + 1e-8, +inf after a miss, 0 for
+ * none).  The lists depend on the Gaussians' geometry and the camera only: they stay valid across samples
+ * while neither changes.
  *   flags of rtgs_peel: RTGS_PEEL_FRESH = the sample starts with this peel (attenuation 1 instead of the
  *   buffer's contents: the clear_attenuation of ray_tracer.py:46). */
 #define RTGS_PEEL_FRESH 1u
@@ -267,14 +268,19 @@ int rtgs_shard_frame(const RtgsScene* scene, const RtgsCamera* cam, const RtgsTr
                      rtgs_stream_t render_stream, void* reuse_event, void* traced_event,
                      rtgs_stream_t consumer_stream, int32_t consumer_waits);
 
-/* One frame whose projection runs on a stream of its own (ABI v6): [project_stream waits for reuse_event, the last
- * trace that read `workspace`, unless complete or NULL] -> rtgs_project_shard there -> projected_event ->
- * [trace_stream waits for it] -> rtgs_trace(projected = 1) there -> traced_event (may be NULL).  With two
- * workspaces in alternation frame f+1's k_project / k_bin run while frame f's k_trace still fills the chip. */
-int rtgs_frame_ahead(const RtgsScene* scene, const RtgsCamera* cam, const RtgsTraceParams* params, float* out,
-                     float* attenuation_buf, float* ray_start, void* workspace, size_t workspace_bytes,
-                     rtgs_stream_t project_stream, rtgs_stream_t trace_stream, void* reuse_event, void* projected_event,
-                     void* traced_event);
+/* B frames of one shard, render side, in ONE call (ABI v7): for frame k = 0 .. n_frames-1, rtgs_project + rtgs_trace of
+ * the shard seen from cams[k] (HOST array of poses) into outs[k] (HOST array of device pointers) on
+ * render_streams[(first_stream + k) % n_streams], with workspaces[that stream] (and attenuation_bufs / ray_starts
+ * [that stream] for depth > RTGS_MAX_DEPTH; both arrays may be NULL otherwise).  Every stream used first waits for
+ * reuse_event (the previous reader of the buffers behind outs[]; NULL or complete: no wait), records
+ * done_events[stream] after its last frame of the call, and consumer_stream is made to wait for those events when
+ * consumer_waits != 0.  The reference renders one pose per loop iteration (__main__.py:236-257); a turntable or a
+ * benchmark that knows its next B poses pays one library call -- and, in rtgs.parallel, one collective -- per B frames. */
+int rtgs_shard_frames(const RtgsScene* scene, const RtgsCamera* cams, int32_t n_frames, const RtgsTraceParams* params,
+                      float* const* outs, float* const* attenuation_bufs, float* const* ray_starts,
+                      void* const* workspaces, size_t workspace_bytes, const rtgs_stream_t* render_streams,
+                      int32_t n_streams, int32_t first_stream, void* reuse_event, void* const* done_events,
+                      rtgs_stream_t consumer_stream, int32_t consumer_waits);
 
 /* Destination side, after the gather was queued on `stream`: records sent_event there (the senders'
  * buffers may be reused once it completes; may be NULL), then scatters the first n_land of `batch`

@@ -185,6 +185,23 @@ def gaussian_cov(rotation, scale, dtype=np.float64):
     return (rs @ np.swapaxes(smat, -1, -2)) @ np.swapaxes(r, -1, -2)
 
 
+def gaussian_bounding_box(position, rotation, scale, threshold=3.0, dtype=np.float64):
+    """gaussian.py:104-138 -- the AABB of the six points position +- R (S (threshold e_k)), k = x, y, z: the end
+    points of the ellipsoid's axes at `threshold` (BOUNDING_THRESHOLD = 3, gaussian.py:13) scale units, NOT the
+    ellipsoid's tight box (the reference's own TODO, :112).  Returns (p_min, p_max)."""
+    r = quat_as_rotation_mat3(rotation, dtype)
+    s = _a(scale, dtype)
+    p = _a(position, dtype)
+    pts = []
+    for k in range(3):
+        e = np.zeros(s.shape[:-1] + (3,), dtype=dtype)
+        e[..., k] = threshold
+        arm = (r @ (s * e)[..., None])[..., 0]
+        pts += [p + arm, p - arm]
+    pts = np.stack(pts, axis=0)
+    return pts.min(axis=0), pts.max(axis=0)
+
+
 def mat3_inverse(m, dtype=np.float64):
     """ti.math.inverse on a 3x3 (gaussian.py:196, 215): adjugate / determinant, in `dtype`."""
     m = _a(m, dtype)

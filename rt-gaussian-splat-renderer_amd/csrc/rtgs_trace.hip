@@ -94,8 +94,9 @@ namespace {
 // 0.2905 -> 0.2595 ms).  Measured and dropped again: SH coefficients staged per wave and list position (0.291 -> 0.325
 // ms); the per-workgroup staging for the 1 M-Gaussian form (129 VGPRs: c5 1.293 -> 1.42 capped at 128) and with slots 48
 // floats apart (four-way bank conflicts: no gain at all); explicit fmaf chains in the 1 M-Gaussian form's gather (141
-// VGPRs); the next frame's projection on a stream of its own, also at the lowest priority (rtgs_frame_ahead: 0.1502 ->
-// 0.1542 ms per c3 frame: a dependency across two hardware queues costs more than the 17 us of kernels it hides).
+// VGPRs); the next frame's projection on a stream of its own, also at the lowest priority (one library call with raw
+// events, removed in round 5: 0.1502 -> 0.1542 ms per c3 frame: a dependency across two hardware queues costs more than
+// the 17 us of kernels it hides).
 #ifndef RTGS_STAMPS
 #define RTGS_STAMPS 0     // diagnostic build: per-phase s_memtime stamps of wave 0 into the buffer
 #endif                    // passed as attenuation_buf (8 x u64 per block); never quote its run time
@@ -252,10 +253,11 @@ struct TraceArgs {
   int32_t bin_stride, bin_shift, bin_sx;
   const int32_t* tile_bin;    // [tiles][kTileBinCap] or NULL: per-macro-tile lists, valid where the supertile's bin is
   // peel lists (rtgs_trace_lists) or NULL: instead of compositing, the launch stores every pixel's sorted DISTINCT
-  // entries -- [tile][RTGS_MAX_DEPTH][256 threads] Gaussian index (-1 = no such entry), exponent, t1 -- for rtgs_peel
+  // entries -- a count per pixel and [tile][RTGS_MAX_DEPTH][256 threads] Gaussian index, exponent, t1 -- for rtgs_peel
+  int32_t* list_cnt;  // [tile][256 threads]: how many entries the pixel's list holds (no terminators: slots beyond are never written)
   int32_t* list_idx;
   float* list_w;
-  float* list_t;
+  float* list_t;      // (only rtgs_peel_start reads it)
 };
 
 #if RTGS_COUNT
@@ -1767,9 +1769,9 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
           --left;
         }
       }
-#pragma unroll
-      for (int k = 0; k < kK; ++k)
-        if (k >= cnt) ea->list_idx[lbase + (size_t)k * kTraceBlock] = -1;
+      // the list's length instead of a terminator in every unused slot (round 5: 64 B of index plane per pixel were
+      // written whatever the list held; now 4 B + 12 B per entry)
+      ea->list_cnt[(size_t)tile_l * kTraceBlock + (size_t)(sub * kWave + lane_e)] = cnt;
       return;
     }
   }
@@ -2060,6 +2062,7 @@ struct PeelArgs {
   float inv_fx, inv_fy;
   float rc[9];
   const FrameCam* pose;
+  const int32_t* list_cnt;
   const int32_t* list_idx;
   const float* list_w;
   float* sample;
@@ -2079,12 +2082,12 @@ __global__ __launch_bounds__(kTraceBlock) void k_peel(const PeelArgs a, const fl
   const int pj = (tile / a.tiles_x) * kTile + (sub / kWavesX) * kWaveTile + (lane & 7);
   if (pi >= a.width || pj >= a.height) return;
   const size_t at = ((size_t)tile * RTGS_MAX_DEPTH + a.k) * kTraceBlock + tid;
-  const int gi = a.list_idx[at];
   const size_t pix = (size_t)pi * a.height + pj;
-  if (gi < 0) {                      // a miss (ray_tracer.py:103-104): nothing to add
+  if (a.k >= a.list_cnt[(size_t)tile * kTraceBlock + tid]) {   // a miss (ray_tracer.py:103-104): nothing to add
     if (a.fresh) a.att[pix] = 1.0f;
     return;
   }
+  const int gi = a.list_idx[at];
   const float wk = a.list_w[at];
   float T = a.fresh ? 1.0f : a.att[pix];
   float4 co = colop[gi];
@@ -2115,7 +2118,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_peel(const PeelArgs a, const fl
 // cam_ray_field.start after `done` peels of the listed sample (ray_tracer.py:99-104): t1 of the last peel
 // + 1e-8, +inf once a peel has missed, 0 before the first
 __global__ __launch_bounds__(kTraceBlock) void k_peel_start(int32_t width, int32_t height, int32_t tiles_x, int32_t done,
-                                                             const int32_t* __restrict__ list_idx,
+                                                             const int32_t* __restrict__ list_cnt,
                                                              const float* __restrict__ list_t,
                                                              float* __restrict__ start, int32_t stride) {
   const int tid = threadIdx.x, lane = tid & (kWave - 1), sub = tid >> 6;
@@ -2126,7 +2129,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_peel_start(int32_t width, int32
   float s_out = 0.f;
   if (done > 0) {
     const size_t at = ((size_t)tile * RTGS_MAX_DEPTH + (done - 1)) * kTraceBlock + tid;
-    s_out = list_idx[at] >= 0 ? list_t[at] + 1e-8f : kInf;
+    s_out = done <= list_cnt[(size_t)tile * kTraceBlock + tid] ? list_t[at] + 1e-8f : kInf;
   }
   start[((size_t)pi * height + pj) * stride] = s_out;
 }
@@ -2393,6 +2396,19 @@ extern "C" int rtgs_project_shard(const RtgsScene* scene, const RtgsCamera* cam,
   return project_impl(scene, cam, workspace, workspace_bytes, stream, shard_wants_bins(cam, local));
 }
 
+// peel lists: [count per pixel: tiles x 256 int32][index plane][exponent plane][t1 plane], the three planes
+// [tile][RTGS_MAX_DEPTH][256 threads]
+struct PeelLists { int32_t* cnt; int32_t* idx; float* w; float* t; };
+static PeelLists peel_lists_of(void* lists, int32_t width, int32_t height) {
+  const size_t tiles = (size_t)rtgs_num_tiles(width, height), slots = tiles * RTGS_MAX_DEPTH * kTraceBlock;
+  PeelLists p;
+  p.cnt = static_cast<int32_t*>(lists);
+  p.idx = p.cnt + tiles * kTraceBlock;
+  p.w = reinterpret_cast<float*>(p.idx + slots);
+  p.t = p.w + slots;
+  return p;
+}
+
 // tile_limit caps the number of (tile_first, tile_step) tiles the launch covers (rtgs_render's
 // row ranges); rtgs_trace passes "all of them".
 static int trace_impl(const RtgsScene* scene, const RtgsCamera* cam, const RtgsTraceParams* params,
@@ -2485,12 +2501,10 @@ static int trace_impl(const RtgsScene* scene, const RtgsCamera* cam, const RtgsT
   a.start = ray_start;
   a.start_stride = ray_start ? ray_start_stride : 1;
   a.tile_order = params->tile_order;
-  a.list_idx = nullptr; a.list_w = nullptr; a.list_t = nullptr;
+  a.list_cnt = nullptr; a.list_idx = nullptr; a.list_w = nullptr; a.list_t = nullptr;
   if (lists) {
-    const size_t slots = (size_t)rtgs_num_tiles(cam->width, cam->height) * RTGS_MAX_DEPTH * kTraceBlock;
-    a.list_idx = static_cast<int32_t*>(lists);
-    a.list_w = reinterpret_cast<float*>(a.list_idx + slots);
-    a.list_t = a.list_w + slots;
+    const PeelLists pl = peel_lists_of(lists, cam->width, cam->height);
+    a.list_cnt = pl.cnt; a.list_idx = pl.idx; a.list_w = pl.w; a.list_t = pl.t;
   }
   a.idx_bits = 1;
   while (a.idx_bits < 31 && (1u << a.idx_bits) < (uint32_t)scene->n) ++a.idx_bits;
@@ -2543,7 +2557,8 @@ int rtgs_trace(const RtgsScene* scene, const RtgsCamera* cam, const RtgsTracePar
 // entries, rtgs_peel composites entry k of every ray, rtgs_peel_start writes the ray.start the peels so far imply.
 
 size_t rtgs_peel_list_bytes(int32_t width, int32_t height) {
-  return (size_t)rtgs_num_tiles(width, height) * RTGS_MAX_DEPTH * kTraceBlock * (sizeof(int32_t) + 2 * sizeof(float));
+  return (size_t)rtgs_num_tiles(width, height) * kTraceBlock *
+         (sizeof(int32_t) + RTGS_MAX_DEPTH * (sizeof(int32_t) + 2 * sizeof(float)));
 }
 
 int rtgs_trace_lists(const RtgsScene* scene, const RtgsCamera* cam, const int32_t* tile_order, void* lists,
@@ -2573,15 +2588,14 @@ int rtgs_peel(const RtgsScene* scene, const RtgsCamera* cam, const void* lists, 
   if (lists_bytes < rtgs_peel_list_bytes(cam->width, cam->height)) return RTGS_EWORKSPACE;
   const FrameCam fc = make_frame_cam(*cam);
   const int32_t tiles = rtgs_num_tiles(cam->width, cam->height);
-  const size_t slots = (size_t)tiles * RTGS_MAX_DEPTH * kTraceBlock;
+  const PeelLists pl = peel_lists_of(const_cast<void*>(lists), cam->width, cam->height);
   PeelArgs a;
   a.width = cam->width; a.height = cam->height; a.tiles_x = (cam->width + kTile - 1) / kTile;
   a.k = k; a.fresh = (flags & RTGS_PEEL_FRESH) ? 1u : 0u;
   a.inv_fx = (float)fc.inv_fx; a.inv_fy = (float)fc.inv_fy;
   for (int q = 0; q < 9; ++q) a.rc[q] = (float)fc.rc[q];
   a.pose = static_cast<const FrameCam*>(cam->device_pose);
-  a.list_idx = static_cast<const int32_t*>(lists);
-  a.list_w = reinterpret_cast<const float*>(a.list_idx + slots);
+  a.list_cnt = pl.cnt; a.list_idx = pl.idx; a.list_w = pl.w;
   a.sample = sample_buf; a.att = attenuation_buf;
   const float4* colop = reinterpret_cast<const float4*>(scene->color_opacity);
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -2596,11 +2610,9 @@ int rtgs_peel_start(const RtgsCamera* cam, const void* lists, size_t lists_bytes
   if (peels_done < 0 || peels_done > RTGS_MAX_DEPTH) return RTGS_EDEPTH;
   if (lists_bytes < rtgs_peel_list_bytes(cam->width, cam->height)) return RTGS_EWORKSPACE;
   const int32_t tiles = rtgs_num_tiles(cam->width, cam->height);
-  const size_t slots = (size_t)tiles * RTGS_MAX_DEPTH * kTraceBlock;
-  const int32_t* idx = static_cast<const int32_t*>(lists);
+  const PeelLists pl = peel_lists_of(const_cast<void*>(lists), cam->width, cam->height);
   hipLaunchKernelGGL(k_peel_start, dim3(tiles), dim3(kTraceBlock), 0, static_cast<hipStream_t>(stream), cam->width,
-                     cam->height, (cam->width + kTile - 1) / kTile, peels_done, idx,
-                     reinterpret_cast<const float*>(idx + slots) + slots, ray_start, ray_start_stride);
+                     cam->height, (cam->width + kTile - 1) / kTile, peels_done, pl.cnt, pl.t, ray_start, ray_start_stride);
   return check_launch();
 }
 
@@ -2670,32 +2682,51 @@ int rtgs_shard_frame(const RtgsScene* scene, const RtgsCamera* cam, const RtgsTr
   return RTGS_OK;
 }
 
-// One frame with its projection on a stream of its own: [project_stream waits for reuse_event -- the last trace that
-// read this workspace -- unless it is complete or NULL] -> rtgs_project_shard on project_stream -> projected_event ->
-// [trace_stream waits for it] -> rtgs_trace(projected) on trace_stream -> traced_event (may be NULL).  A caller that
-// alternates two workspaces gets frame f+1's k_project / k_bin (latency-bound, a few CUs) executed while frame f's
-// k_trace still fills the chip.
-int rtgs_frame_ahead(const RtgsScene* scene, const RtgsCamera* cam, const RtgsTraceParams* params, float* out,
-                     float* attenuation_buf, float* ray_start, void* workspace, size_t workspace_bytes,
-                     rtgs_stream_t project_stream, rtgs_stream_t trace_stream, void* reuse_event, void* projected_event,
-                     void* traced_event) {
-  if (!params || !cam || !projected_event) return RTGS_EINVAL;
-  hipStream_t ps = static_cast<hipStream_t>(project_stream), ts = static_cast<hipStream_t>(trace_stream);
-  if (reuse_event && hipEventQuery(static_cast<hipEvent_t>(reuse_event)) != hipSuccess) {
+// B frames of one shard, render side, in ONE call (ABI v7; VERDICT r4 #1b): the tile-parallel loop is host-bound at 8
+// ranks (a 1/8 shard of a 1080p frame traces in ~20 us of throughput while a Python frame loop costs ~30 us), so the
+// caller hands over a HOST array of camera poses and the library queues, for frame k = 0 .. n_frames-1,
+// rtgs_project + rtgs_trace of the shard on render_streams[(first_stream + k) % n_streams] with that stream's
+// workspace (and per-pixel state for depth > RTGS_MAX_DEPTH) into outs[k].  Before its first frame every stream used
+// waits for reuse_event (the previous reader of the buffers outs[] point into; skipped when complete or NULL); after
+// its last one it records done_events[stream] and -- consumer_waits != 0 -- consumer_stream is made to wait for it.
+// Frames on one stream are ordered, so n_streams events order the whole batch.
+int rtgs_shard_frames(const RtgsScene* scene, const RtgsCamera* cams, int32_t n_frames, const RtgsTraceParams* params,
+                      float* const* outs, float* const* attenuation_bufs, float* const* ray_starts,
+                      void* const* workspaces, size_t workspace_bytes, const rtgs_stream_t* render_streams,
+                      int32_t n_streams, int32_t first_stream, void* reuse_event, void* const* done_events,
+                      rtgs_stream_t consumer_stream, int32_t consumer_waits) {
+  if (!cams || !outs || !workspaces || !render_streams || !done_events || n_frames < 0 || n_streams <= 0 ||
+      first_stream < 0)
+    return RTGS_EINVAL;
+  if (n_frames == 0) return RTGS_OK;
+  const int32_t used = n_frames < n_streams ? n_frames : n_streams;
+  for (int32_t u = 0; u < used; ++u)
+    if (!done_events[(first_stream + u) % n_streams]) return RTGS_EINVAL;
+  const bool reuse_pending = reuse_event && hipEventQuery(static_cast<hipEvent_t>(reuse_event)) != hipSuccess;
+  if (reuse_pending) {
     (void)hipGetLastError();
-    if (hipStreamWaitEvent(ps, static_cast<hipEvent_t>(reuse_event), 0) != hipSuccess) return RTGS_EDEVICE;
+    for (int32_t u = 0; u < used; ++u)
+      if (hipStreamWaitEvent(static_cast<hipStream_t>(render_streams[(first_stream + u) % n_streams]),
+                             static_cast<hipEvent_t>(reuse_event), 0) != hipSuccess)
+        return RTGS_EDEVICE;
   }
-  const bool listed = (params->flags & RTGS_TRACE_TILE_LIST) != 0;
-  const int32_t local = listed ? params->tile_count
-                               : rtgs_num_local_tiles(cam->width, cam->height, params->tile_first, params->tile_step);
-  if (int rc = project_impl(scene, cam, workspace, workspace_bytes, project_stream, shard_wants_bins(cam, local),
-                            (params->flags & RTGS_TRACE_REGION) ? params->region : nullptr)) return rc;
-  if (hipEventRecord(static_cast<hipEvent_t>(projected_event), ps) != hipSuccess) return RTGS_EDEVICE;
-  if (hipStreamWaitEvent(ts, static_cast<hipEvent_t>(projected_event), 0) != hipSuccess) return RTGS_EDEVICE;
-  if (int rc = trace_impl(scene, cam, params, out, attenuation_buf, ray_start, 1, workspace, workspace_bytes, 1, INT32_MAX,
-                          trace_stream))
-    return rc;
-  if (traced_event && hipEventRecord(static_cast<hipEvent_t>(traced_event), ts) != hipSuccess) return RTGS_EDEVICE;
+  // an EMPTY share (explicit tile list of no tiles) renders nothing: its frames only take part in the event chain
+  const bool empty_share = params && (params->flags & RTGS_TRACE_TILE_LIST) && params->tile_count == 0;
+  for (int32_t k = 0; k < n_frames && !empty_share; ++k) {
+    const int32_t si = (first_stream + k) % n_streams;
+    if (!outs[k]) return RTGS_EINVAL;
+    if (int rc = trace_impl(scene, &cams[k], params, outs[k], attenuation_bufs ? attenuation_bufs[si] : nullptr,
+                            ray_starts ? ray_starts[si] : nullptr, 1, workspaces[si], workspace_bytes, 0, INT32_MAX,
+                            render_streams[si]))
+      return rc;
+  }
+  for (int32_t u = 0; u < used; ++u) {
+    const int32_t si = (first_stream + u) % n_streams;
+    hipEvent_t ev = static_cast<hipEvent_t>(done_events[si]);
+    if (hipEventRecord(ev, static_cast<hipStream_t>(render_streams[si])) != hipSuccess) return RTGS_EDEVICE;
+    if (consumer_waits && hipStreamWaitEvent(static_cast<hipStream_t>(consumer_stream), ev, 0) != hipSuccess)
+      return RTGS_EDEVICE;
+  }
   return RTGS_OK;
 }
 

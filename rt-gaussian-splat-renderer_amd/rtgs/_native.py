@@ -14,7 +14,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_size_t, c_u
 
 import torch  # noqa: F401  (must precede the CDLL load, see module docstring)
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_DEPTH = 16
 RAY_FLOATS = 8
 SH_COEFFS = 15
@@ -40,6 +40,18 @@ class RtgsScene(Structure):
 class RtgsCamera(Structure):
     _fields_ = [("position", c_float * 3), ("rotation", c_float * 4), ("width", c_int32),
                 ("height", c_int32), ("fx", c_float), ("fy", c_float), ("device_pose", c_void_p)]
+
+
+def _camera_dtype():
+    """RtgsCamera as a NumPy record (HOST arrays of poses for rtgs_shard_frames are filled through it)."""
+    import numpy as np
+    dt = np.dtype([("position", "<f4", 3), ("rotation", "<f4", 4), ("width", "<i4"), ("height", "<i4"),
+                   ("fx", "<f4"), ("fy", "<f4"), ("device_pose", "<u8")], align=True)
+    assert dt.itemsize == ctypes.sizeof(RtgsCamera) and dt.fields["device_pose"][1] == RtgsCamera.device_pose.offset
+    return dt
+
+
+CAMERA_DTYPE = _camera_dtype()
 
 
 class RtgsTraceParams(Structure):
@@ -83,8 +95,9 @@ PROTOTYPES = {
     "rtgs_shard_frame": (c_int32, [POINTER(RtgsScene), POINTER(RtgsCamera), POINTER(RtgsTraceParams), c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_int32]),
-    "rtgs_frame_ahead": (c_int32, [POINTER(RtgsScene), POINTER(RtgsCamera), POINTER(RtgsTraceParams), c_void_p, c_void_p,
-                                   c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rtgs_shard_frames": (c_int32, [POINTER(RtgsScene), c_void_p, c_int32, POINTER(RtgsTraceParams), c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
+                                    c_void_p, c_int32]),
     "rtgs_frames_land": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                    c_void_p, c_void_p]),
     "rtgs_frames_land_map": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,

@@ -10,6 +10,7 @@ functions in the reference and run HIP kernels here (include/rtgs_hip.h); there 
 from __future__ import annotations
 
 import math
+from typing import NamedTuple
 
 import numpy as np
 import torch
@@ -19,6 +20,18 @@ from .ray import Ray
 from .utils.types import vec2, vec3, vec4
 
 BOUNDING_THRESHOLD = 3  # gaussian.py:13: squared Mahalanobis radius of the hit ellipsoid
+
+
+class Bound(NamedTuple):
+    """bounding_box.py:5-13: (p_min, p_max) of an axis-aligned box."""
+    p_min: np.ndarray
+    p_max: np.ndarray
+
+    def get_centroid(self):      # bounding_box.py:21-22
+        return vec3(0.5 * (self.p_min + self.p_max))
+
+    def size(self):              # bounding_box.py:24-26
+        return vec3(self.p_max - self.p_min)
 
 SH_NAMES = ("sh_10", "sh_11", "sh_12", "sh_20", "sh_21", "sh_22", "sh_23", "sh_24",
             "sh_30", "sh_31", "sh_32", "sh_33", "sh_34", "sh_35", "sh_36")  # gaussian.py:41-55
@@ -107,10 +120,18 @@ class Gaussian:
         """Degree 1..3 SH radiance for a NORMALISED dir (gaussian.py:140-181)."""
         return vec3(self._eval(self.position, dir, (0, 0, 0), 1.0)[:3])
 
-    def bounding_box(self):
-        """gaussian.py:104-138 feeds only the reference's BVH build, which this path replaces
-        by per-frame screen bounds (SURVEY.md 8(f) #3)."""
-        raise NotImplementedError("Gaussian.bounding_box is BVH-only and out of this path's scope")
+    def bounding_box(self) -> "Bound":
+        """Axis-aligned box of the six end points position +- R S (3 e_k) of the ellipsoid's axes
+        (gaussian.py:104-138; BOUNDING_THRESHOLD = 3 scale units, conservative-but-loose by the reference's own
+        TODO at :112).  Only the reference's BVH build consumes it -- this path culls with per-frame screen bounds
+        and exact world boxes of its own (``Scene.accel``) -- but it is on the surface a caller sees.  The rotation
+        matrix comes from the device (``quat.as_rotation_mat3``: rtgs_quat_op), like every other method here."""
+        from .utils import quaternion as quat
+        r = quat.as_rotation_mat3(np.asarray(self.rotation, dtype=np.float32)).cpu().numpy().astype(np.float32)
+        arms = r * (np.float32(BOUNDING_THRESHOLD) * np.asarray(self.scale, dtype=np.float32))[None, :]   # column k = R S (3 e_k)
+        p = np.asarray(self.position, dtype=np.float32)
+        pts = np.concatenate([p[None, :] + arms.T, p[None, :] - arms.T], axis=0)
+        return Bound(vec3(pts.min(axis=0)), vec3(pts.max(axis=0)))
 
     @staticmethod
     def field(shape) -> "GaussianField":

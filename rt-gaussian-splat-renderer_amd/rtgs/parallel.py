@@ -1,15 +1,29 @@
-"""Tile-parallel rendering: one process per GPU, macro-tiles interleaved over ranks, RCCL gather.
+"""Tile-parallel rendering: one process per GPU, macro-tiles interleaved over ranks, RCCL exchange.
 
 The reference is single-process / single-device (no collective anywhere).  Pixels
 are independent, so the frame shards naturally: the T x T macro-tiles (T = rtgs_tile_size())
-are dealt round-robin
-(tile t -> rank t % world), every rank holds the whole scene (one broadcast at load, Gaussians
-are replicated) and renders its tiles into a compact [tiles_per_rank, T, T, 3] buffer, and ONE
-exchange step -- a ``torch.distributed`` gather (backend "nccl" == RCCL over xGMI) of
-W*H*12/world bytes per rank -- lands the shards on the destination rank, where ``rtgs_untile``
-de-interleaves them into the (W, H, 3) framebuffer.  Every rank keeps F frames in flight
-(``TileParallelRenderer``, default 2): frame f is traced on render stream f mod F while the gather of
-the frames before it runs on the caller's stream.
+are dealt round-robin (tile t -> rank t % world), every rank holds the whole scene (one broadcast
+at load, Gaussians are replicated) and renders its tiles into a compact [tiles_per_rank, T, T, 3]
+buffer, and ONE exchange step lands the shards of a frame on its destination rank, where
+``rtgs_untile`` de-interleaves them into the (W, H, 3) framebuffer.  Every rank keeps F frames in
+flight (``TileParallelRenderer``, default 2): frame f is traced on render stream f mod F while the
+exchange of the frames before it runs on the caller's stream.
+
+Where a frame lands (``landing``):
+  "root"    every frame on rank ``dst``: a ``torch.distributed`` gather (backend "nccl" == RCCL over
+            xGMI) of W*H*12/world bytes per rank.  What a single display loop wants
+            (/root/reference's consumer is one, __main__.py:253-257) -- and a bound: the root receives
+            (world-1)/world of every frame, one shard per link, and untiles every frame.
+  "rotate"  (round 5) frame f on rank f mod world.  A batch of B = k * world consecutive frames
+            travels in ONE ``all_to_all_single``: rank r receives, from everybody, the shards of the
+            batch's frames r, r + world, ... -- world gathers with world different roots in one
+            collective, every xGMI link carrying 1/world of what the single root's links carry,
+            every rank untiling one frame in world.  For consumers that can take frames from any
+            rank (an encoder per GPU, a throughput benchmark).
+
+``render_frames(poses)`` queues any number of frames from an array of poses: per batch one library
+call on the render side (``rtgs_shard_frames``: B x [project -> trace] over the F render streams),
+one collective, one landing call (``rtgs_frames_land``).
 
 Round 4: the deal need not be equal.  ``Partition`` names every rank's tiles explicitly (``RtgsTraceParams.tile_list``),
 ``Partition.weighted`` gives every rank its own share, the exchange is then point to point (each shard's own bytes) and
@@ -76,6 +90,7 @@ class Partition:
     as a single MI355X needs to render the whole frame.  A destination that keeps the share x of the tiles that
     balances its own trace against one peer's transfer (``calibrated_shares``) shortens both."""
 
+    MAX_MAPPED_RANKS = 16   # rtgs_frames_land_map / rtgs_untile_map pass the ranks' buffers as kernel arguments
     PERIOD = 64          # weighted deal: tile t belongs to the owner of residue t mod PERIOD
     _SPREAD = 37         # residues are dealt out in the order (i * 37) mod 64, so a rank's tiles do not form runs
 
@@ -162,23 +177,6 @@ def _phase(*what):
     if os.environ.get("RTGS_TRACE_PHASES") == "1":
         import sys
         print(f"[rtgs rank {os.environ.get('RANK', '?')}]", *what, file=sys.stderr, flush=True)
-
-
-def _side_stream(device, priority: str = "low"):
-    """A stream for work that should fill the chip only where the caller's stream leaves it idle (the next frame's
-    projection behind this frame's trace): the LOWEST priority the device offers (torch.cuda.Stream only reaches the
-    normal and the high level), wrapped for torch.  priority="normal": a plain torch stream."""
-    if priority != "low":
-        return torch.cuda.Stream(device=device)
-    import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
-    least, greatest = ctypes.c_int(0), ctypes.c_int(0)
-    if hip.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest)) != 0:
-        return torch.cuda.Stream(device=device)
-    handle = ctypes.c_void_p()
-    if hip.hipStreamCreateWithPriority(ctypes.byref(handle), 1, least.value) != 0:      # 1 = hipStreamNonBlocking
-        return torch.cuda.Stream(device=device)
-    return torch.cuda.ExternalStream(handle.value, device=device)
 
 
 class _Done:
@@ -271,19 +269,8 @@ class HipBackend:
         self._orders = {}
         self._state = {}
         self._scene_native = self._camera_native = None
-        # Optional hipGraph replay of project + trace (RTGS_GRAPH=1).  OFF by default: measured on
-        # MI355X / ROCm 7.2 (tools/graph_vs_direct.py) a replay costs 12 us more per frame than the
-        # two direct launches and holds the host until the graph has run (c3 1/8 shard: 70.9 vs
-        # 58.1 us per frame; direct launches cost the host 13.5 us and overlap the GPU)
-        self.use_graph = os.environ.get("RTGS_GRAPH", "0") == "1"
-        self._graphs = {}
-        # Optional (RTGS_PIPELINE=1): frame f+1's projection on a second stream, into a second
-        # workspace, while frame f is still being traced.  OFF by default: measured on MI355X / ROCm
-        # 7.2 the two cross-stream event waits per frame cost more than the overlap returns -- also as ONE
-        # library call with raw events (rtgs_frame_ahead, round 4): c3 0.1502 -> 0.1547 ms per frame,
-        # c5 1.320 -> 1.344, c2 0.0485 -> 0.0541 with the host queueing 200 frames ahead
-        self.pipeline = os.environ.get("RTGS_PIPELINE", "0") == "1"
-        self._pipe = None
+        # (round 5: the hipGraph replay of project + trace and the projection on a stream of its own -- RTGS_GRAPH /
+        # RTGS_PIPELINE, measured slower in rounds 2, 3 and 4, HISTORY.md -- are gone)
 
     def scene_native(self):
         """``scene.native()`` cached per commit (the struct only holds the streamed tensors' addresses)."""
@@ -392,64 +379,38 @@ class HipBackend:
                                        1 if projected else 0, st),
                   "rtgs_trace")
 
-    # ---- hipGraph path ---------------------------------------------------------------------
-    def frame_graph(self, out, tile_first: int, tile_step: int, compact: bool):
-        """A captured hipGraph of [pose upload, rtgs_project, rtgs_trace] writing into `out`.  The
-        camera pose travels through a device block (RtgsCamera.device_pose) that the graph refreshes
-        from pinned host memory, so a replay renders the pose packed just before it."""
-        key = (out.data_ptr(), tile_first, tile_step, compact)
-        g = self._graphs.get(key)
-        if g is None:
-            g = _FrameGraph(self, out, tile_first, tile_step, compact)
-            self._graphs[key] = g
-        return g
-
     def render(self, out, tile_first: int, tile_step: int, compact: bool, stream=None, workspace=None, shard=None):
-        """project + trace of one shard into `out`: two direct launches on `stream` (default: the
-        current stream) with `workspace` (default: the backend's own), or -- opt-in, current stream
-        only -- a graph replay / the pipelined form."""
-        if stream is None and self.use_graph and shard is None:
-            self.frame_graph(out, tile_first, tile_step, compact).replay()
-        elif stream is None and self.pipeline and shard is None:
-            self._render_pipelined(out, tile_first, tile_step, compact)
-        else:
-            self.trace(out, tile_first, tile_step, compact, stream=stream, workspace=workspace, shard=shard)
+        """project + trace of one shard into `out`: two (three with bins) direct launches on `stream` (default: the
+        current stream) with `workspace` (default: the backend's own)."""
+        self.trace(out, tile_first, tile_step, compact, stream=stream, workspace=workspace, shard=shard)
 
-    def _render_pipelined(self, out, tile_first: int, tile_step: int, compact: bool):
-        """project on a side stream into workspace f & 1, trace on the caller's stream once that projection is
-        done: ONE library call (``rtgs_frame_ahead``: two stream waits, two event records, the launches).  A
-        frame's own latency is what it was (its trace waits for its projection); a host that queues frames ahead
-        of the GPU -- a turntable, bench.py -- gets frame f+1's k_project / k_bin (latency-bound, a few CUs)
-        executed while frame f's k_trace fills the chip.  The pose and the scene pointers are read when the frame
-        is queued, as without the pipeline."""
-        import ctypes
+    # ---- B frames per library call ------------------------------------------------------------
+    def camera_array(self, poses=None, count: int = 1):
+        """A HOST array of RtgsCamera for ``rtgs_shard_frames``: one per pose of `poses` -- a sequence of
+        (position, rotation) or an (n, 7) array x y z qx qy qz qw -- or `count` copies of the camera's current pose.
+        Filled through NumPy (one structured assignment, not n x 11 ctypes stores); returns (array, n): keep the
+        array alive until the call has returned."""
+        import numpy as np
         nat = self.nat
-        lib = nat.lib()
-        if self._pipe is None:
-            def event():
-                h = ctypes.c_void_p()
-                nat.check(lib.rtgs_event_create(ctypes.byref(h)), "rtgs_event_create")
-                return h.value
-            self._pipe = dict(stream=_side_stream(self.device, os.environ.get("RTGS_PIPELINE_PRIO", "low")), turn=0,
-                              ws=[self.workspace, torch.empty_like(self.workspace)],
-                              projected=[event(), event()], traced=[event(), event()], params={})
-        pp = self._pipe
-        k = pp["turn"] & 1
-        pp["turn"] += 1
-        side = pp["stream"]
-        key = self.scene.content_key()
-        if pp.get("scene_key") != key:
-            side.wait_stream(nat.current_stream(self.device.index))   # scene uploads / edits queued on the caller's stream
-            pp["scene_key"] = key
-        pk = (tile_first, tile_step, compact)
-        if pk not in pp["params"]:
-            order = self.tile_order(tile_first, tile_step) if self.use_tile_order else None
-            pp["params"][pk] = (nat.RtgsTraceParams(self.depth, self.t_cutoff, tile_first, tile_step,
-                                                    nat.TRACE_COMPACT if compact else 0, nat.ptr(order)), order)
-        ws = pp["ws"][k]
-        nat.check(lib.rtgs_frame_ahead(self.scene_native(), self.camera_native(), pp["params"][pk][0], nat.ptr(out), None, None,
-                                       nat.ptr(ws), ws.numel(), side.cuda_stream, nat.stream(), pp["traced"][k],
-                                       pp["projected"][k], pp["traced"][k]), "rtgs_frame_ahead")
+        c = self.camera
+        if poses is None:
+            key = (count, bytes(memoryview(c.position)), bytes(memoryview(c.rotation)), bytes(memoryview(c.focal_length)))
+            hit = getattr(self, "_cam_array", None)
+            if hit is not None and hit[0] == key:
+                return hit[1], count
+            pose = np.concatenate([np.asarray(c.position, np.float32), np.asarray(c.rotation, np.float32)])[None, :]
+            pose = np.repeat(pose, count, axis=0)
+        else:
+            pose = _pose_rows(poses)
+            key = None
+        n = int(pose.shape[0])
+        arr = np.zeros(n, dtype=nat.CAMERA_DTYPE)
+        arr["position"], arr["rotation"] = pose[:, :3], pose[:, 3:]
+        arr["width"], arr["height"] = self.width, self.height
+        arr["fx"], arr["fy"] = float(c.focal_length[0]), float(c.focal_length[1])
+        if key is not None:
+            self._cam_array = (key, arr)
+        return arr, n
 
     def untile(self, gathered, world: int, tiles_per_rank: int, image, stream=None):
         nat = self.nat
@@ -468,54 +429,39 @@ class HipBackend:
                                             nat.ptr(image), st), "rtgs_untile_map")
 
 
-class _FrameGraph:
-    """One captured frame of one shard (see HipBackend.frame_graph): the graph holds rtgs_project +
-    rtgs_trace; the pose block they read is refreshed before every replay by one async copy from a
-    small ring of pinned host blocks, so the host never waits for the GPU."""
+def _pose_rows(poses):
+    """(n, 7) float32 rows x y z qx qy qz qw from (position, rotation) pairs or an array of that shape."""
+    import numpy as np
+    if isinstance(poses, (list, tuple)) and poses and len(poses[0]) == 2:
+        poses = [[*p[0], *p[1]] for p in poses]
+    rows = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 7) if len(poses) else np.zeros((0, 7), np.float32)
+    return rows
 
-    RING = 4
 
-    def __init__(self, backend: HipBackend, out, tile_first, tile_step, compact):
-        nat = backend.nat
-        self.b = backend
-        nbytes = nat.lib().rtgs_pose_bytes()
-        self.pose_host = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(self.RING)]
-        self.copied = [torch.cuda.Event() for _ in range(self.RING)]   # the copy out of block k is done
-        self.pose_dev = torch.empty(nbytes, dtype=torch.uint8, device=backend.device)
-        self.turn = 0
-        self._upload()
-        order = backend.tile_order(tile_first, tile_step) if backend.use_tile_order else None
-        flags = nat.TRACE_COMPACT if compact else 0
-        params = nat.RtgsTraceParams(backend.depth, backend.t_cutoff, tile_first, tile_step, flags, nat.ptr(order))
-        scene = backend.scene.native()
-        self.scene_version = backend.scene.version
-        ncam = backend.camera.native(device_pose=self.pose_dev.data_ptr())
-        self.graph = torch.cuda.CUDAGraph()
-        torch.cuda.synchronize()
-        with torch.cuda.graph(self.graph):
-            nat.check(nat.lib().rtgs_trace(scene, ncam, params, nat.ptr(out), None, None, 1,
-                                           nat.ptr(backend.workspace), backend.workspace.numel(), 0,
-                                           nat.stream()), "rtgs_trace (capture)")
-        self._keep = (order, params, scene, ncam)
+def _no_all_to_all(output, input, output_split_sizes=None, input_split_sizes=None, group=None):
+    """Stand-in for dist.all_to_all_single while the compute side of the loop is being timed."""
+    return None
 
-    def _upload(self):
-        nat = self.b.nat
-        k = self.turn % self.RING
-        self.turn += 1
-        self.copied[k].synchronize()        # RING frames old: long complete
-        nat.check(nat.lib().rtgs_pose_pack(self.b.camera.native(), self.pose_host[k].data_ptr()), "rtgs_pose_pack")
-        self.pose_dev.copy_(self.pose_host[k], non_blocking=True)
-        self.copied[k].record()
 
-    def replay(self):
-        if self.scene_version != self.b.scene.version:
-            raise RuntimeError("the scene was re-committed after this frame graph was captured")
-        self._upload()
-        self.graph.replay()
+def _all_to_all(output, input, output_split_sizes=None, input_split_sizes=None, group=None):
+    """``dist.all_to_all_single`` on the current stream (RCCL: one grouped send / recv to and from every peer, all links
+    at once).  Over gloo with device tensors -- the one-GPU rehearsal of the N > 1 path, never a measurement --
+    the blocks are staged through the host."""
+    if input.is_cuda and dist.get_backend(group) == "gloo":
+        host_out = torch.empty(output.shape, dtype=output.dtype)
+        dist.all_to_all_single(host_out, input.cpu(), output_split_sizes, input_split_sizes, group=group)
+        output.copy_(host_out)
+        return None
+    return dist.all_to_all_single(output, input, output_split_sizes, input_split_sizes, group=group)
 
 
 class TileParallelRenderer:
-    """Renders whole frames on `world` ranks; the image lands in ``framebuffer`` on rank `dst`.
+    """Renders whole frames on `world` ranks; where they land is ``landing``:
+
+    ``"root"`` (default): every frame in ``framebuffer`` on rank `dst`, by one gather per batch.
+    ``"rotate"``: frame f on rank f mod world, by ONE ``all_to_all_single`` per batch of B = k * world frames --
+    every rank is the root of k of the batch's frames (``landed_frames()`` names them), every xGMI link carries
+    1/world of the single root's inbound traffic and every rank untiles one frame in world.
 
     ``frames_in_flight`` (default 2, ``RTGS_FRAMES_IN_FLIGHT``): a 1/8 shard of a 1080p frame is ONE
     resident round of workgroups, so its trace takes as long as its heaviest tile's dependency chain
@@ -523,28 +469,38 @@ class TileParallelRenderer:
     With F frames in flight every rank alternates its frames over F render streams, each with its
     own workspace, so consecutive frames' traces overlap (two 1/8-shard traces: 43.5 us per pair
     against 74.3 one after the other, tools/concurrency_probe.py) and the loop is bound by
-    throughput, not by one tile's latency.  Each frame costs its render stream exactly one event
-    record; the gather and the untile stay on the caller's stream, in frame order.  The render side
-    of a frame is ONE library call (``rtgs_shard_frame``: reuse wait, project, trace, event record,
-    consumer wait), the landing side another (``rtgs_frames_land``: event record + untile).
+    throughput, not by one tile's latency.  The exchange and the untile stay on the caller's stream, in frame order.
 
-    ``gather_batch`` (default 1, ``RTGS_GATHER_BATCH``): B consecutive frames' shards travel in one
-    collective (each rank sends [B][tiles][T][T][3]) and land in a ring of B framebuffers, the
-    newest being ``framebuffer``: the collective's fixed host and launch cost (16-26 us per call,
-    more than a 1/8-shard trace of a 1080p frame) is paid once per B frames, at the price of B - 1
-    frames of latency.  ``finish()`` flushes a partial batch."""
+    ``gather_batch`` (``RTGS_GATHER_BATCH``; default 1 for "root", the smallest multiple of world >= 8 for
+    "rotate", where it is rounded up to a multiple of world): B consecutive frames' shards travel in one
+    collective and land in a ring of framebuffers, the newest being ``framebuffer``: the collective's fixed host
+    and launch cost (16-26 us per call, more than a 1/8-shard trace of a 1080p frame) is paid once per B frames,
+    at the price of B - 1 frames of latency.  ``finish()`` flushes a partial batch.
+
+    ``render_frames(poses)`` queues many frames at once: per batch ONE library call on the render side
+    (``rtgs_shard_frames``: every frame's project + trace, spread over the F render streams, from a host array
+    of poses), one collective, one landing call (``rtgs_frames_land``).  ``render_frame()`` is
+    ``render_frames(count=1)`` with the camera's current pose."""
 
     def __init__(self, scene=None, camera=None, depth: int = 16, rank: int = 0, world: int = 1,
                  t_cutoff: float = 0.0, dst: int = 0, group=None, backend=None, gather_fn=None,
-                 frames_in_flight: int | None = None, gather_batch: int | None = None, partition=None, p2p_fn=None):
-        """``partition``: None / "equal" = the round-robin deal (equal shards, one ``dist.gather``); a ``Partition``
-        or a sequence of per-rank shares = that deal (point-to-point exchange of each shard's own bytes); "auto" =
-        ``calibrated_shares`` (every rank must construct its renderer at the same time: it times one shard trace,
-        one frame trace and one exchange on this machine and the destination broadcasts the shares)."""
+                 frames_in_flight: int | None = None, gather_batch: int | None = None, partition=None, p2p_fn=None,
+                 landing: str = "root", a2a_fn=None):
+        """``partition``: None / "equal" = the round-robin deal (equal shards, one collective); a ``Partition``
+        or a sequence of per-rank shares = that deal (exchange of each shard's own bytes); "auto" =
+        ``calibrated_shares`` (landing "root" only -- with rotating roots every rank is a destination as often as
+        any other and the equal deal is the balanced one; every rank must construct its renderer at the same time:
+        it times one shard trace, one frame trace and one exchange on this machine and the destination broadcasts
+        the shares)."""
         self.backend = backend if backend is not None else HipBackend(scene, camera, depth, t_cutoff)
         self._gather = gather_fn if gather_fn is not None else dist.gather   # injectable for tests
         self._p2p_fn = p2p_fn                                                # likewise: (mine, landing) -> works
+        self._a2a = a2a_fn if a2a_fn is not None else _all_to_all            # likewise: dist.all_to_all_single's signature
         self.rank, self.world, self.dst, self.group = int(rank), int(world), int(dst), group
+        if landing not in ("root", "rotate"):
+            raise ValueError('landing: "root" or "rotate"')
+        self.landing = landing if self.world > 1 else "root"
+        rot = self.landing == "rotate"
         b = self.backend
         self.TILE = int(b.tile)
         self.total_tiles = tiles_of(b.width, b.height, self.TILE)
@@ -553,7 +509,7 @@ class TileParallelRenderer:
             partition = Partition.wedges(b.width, b.height, self.TILE, self.world)
         if isinstance(partition, str) and partition == "auto":
             partition = None
-            if self.world > 1:
+            if self.world > 1 and not rot:
                 self.calibration = calibrated_shares(b, self.rank, self.world, self.dst, self.group)
                 if not self.calibration["equal"]:
                     partition = self.calibration["shares"]
@@ -563,39 +519,65 @@ class TileParallelRenderer:
             partition = Partition.weighted(self.total_tiles, partition)
         if partition.world != self.world or partition.total != self.total_tiles:
             raise ValueError("partition is of another frame / world size")
-        _phase("deal", partition.name, "local tiles", partition.counts[self.rank])
+        if not partition.arithmetic and self.world > Partition.MAX_MAPPED_RANKS:
+            raise ValueError(f"an explicit tile deal lands through rtgs_frames_land_map, which takes at most "
+                             f"{Partition.MAX_MAPPED_RANKS} ranks; world = {self.world} (the round-robin deal has no limit)")
+        _phase("deal", partition.name, "landing", self.landing, "local tiles", partition.counts[self.rank])
         self.partition = partition
         self.tiles_per_rank = (self.total_tiles + self.world - 1) // self.world     # the arithmetic deal's padded shard
         self.local_tiles = partition.counts[self.rank]
-        # any other deal: this rank's tile list (device), the frame's tile -> (rank, slot) map (destination)
+        is_dst = self.world == 1 or rot or self.rank == self.dst
+        # any other deal: this rank's tile list (device), the frame's tile -> (rank, slot) map (destinations)
         self._shard = self._tile_map = None
         if not partition.arithmetic:
             self._shard = (b.shard(partition.tiles[self.rank], region=partition.compact) if hasattr(b, "shard")
                            else dict(tiles=partition.tiles[self.rank]))
-            if self.world == 1 or self.rank == self.dst:
+            if is_dst:
                 self._tile_map = b.to_device(partition.tile_map) if hasattr(b, "to_device") else partition.tile_map
         if frames_in_flight is None:
             frames_in_flight = int(os.environ.get("RTGS_FRAMES_IN_FLIGHT", "2"))
         if gather_batch is None:
-            gather_batch = int(os.environ.get("RTGS_GATHER_BATCH", "1"))
+            env = os.environ.get("RTGS_GATHER_BATCH")
+            gather_batch = int(env) if env else (max(8, self.world) if rot else 1)
         if frames_in_flight < 1 or gather_batch < 1:
             raise ValueError("frames_in_flight and gather_batch must be >= 1")
         streams = (self.world > 1 and isinstance(b, HipBackend) and
                    os.environ.get("RTGS_RENDER_STREAM", "1") != "0")
         self.frames_in_flight = int(frames_in_flight) if self.world > 1 else 1
-        self.gather_batch = int(gather_batch) if streams else 1
-        is_dst = self.world == 1 or self.rank == self.dst
-        self._fbs = [b.alloc(b.width, b.height, 3) for _ in range(self.gather_batch)] if is_dst else []
+        N = self.world
+        if rot:
+            gather_batch = (int(gather_batch) + N - 1) // N * N      # k whole frames per destination and batch
+        self.gather_batch = int(gather_batch) if (streams or rot) else 1
+        self.per_dest = self.gather_batch // N if rot else self.gather_batch    # k: frames a destination lands per batch
+        self._fbs = [b.alloc(b.width, b.height, 3) for _ in range(self.per_dest)] if is_dst else []
         self._landed = 0            # which of _fbs holds the newest frame
+        self._landed_frames = []    # (frame number, index into _fbs) of the batch that landed last on this rank
         self._pending = []          # one-stream form: (work, slot) of the gathers not yet completed
         self._frame = 0
         self._comm = None
         if self.world > 1:
-            F, B = self.frames_in_flight, self.gather_batch
+            F, B, T = self.frames_in_flight, self.gather_batch, self.TILE
             arith = partition.arithmetic
-            shard = ((self.tiles_per_rank if arith else max(self.local_tiles, 1)), self.TILE, self.TILE, 3)
-            peer = lambda r: (max(partition.counts[r], 1), self.TILE, self.TILE, 3)
-            if streams:
+            E = T * T * 3
+            # rotating roots exchange exact sizes (all_to_all_single with split sizes); the single root's point-to-point
+            # buffers keep at least one tile so that no tensor is empty
+            own = self.tiles_per_rank if arith else (self.local_tiles if rot else max(self.local_tiles, 1))
+            shard = (own, T, T, 3)
+            peer = lambda r: (max(partition.counts[r], 1), T, T, 3)
+            self._split_out = self._split_in = self._recv_off = None
+            if rot:
+                k = self.per_dest
+                self._slots = ((2 * F + B - 1) // B + 1) if streams else 2
+                self.compact = [b.alloc(B, *shard) for _ in range(self._slots)]
+                if arith:
+                    self.gathered = [b.alloc(N * k, *shard) for _ in range(2)]           # [source][k][tiles][T][T][3]
+                else:
+                    self._split_out = [k * c * E for c in partition.counts]
+                    self._split_in = [k * self.local_tiles * E] * N
+                    self._recv_off = [sum(self._split_out[:r]) for r in range(N)]
+                    self.gathered = [b.alloc(max(sum(self._split_out), 1)) for _ in range(2)]   # flat, by source
+                self._glist = []
+            elif streams:
                 # batch-slot ring: deep enough that a render stream never waits for the gather of the
                 # batch it traced into last (only for one S batches back, long done)
                 self._slots = (2 * F + B - 1) // B + 1
@@ -605,8 +587,8 @@ class TileParallelRenderer:
                 if arith:
                     self.gathered = [b.alloc(self.world, B, *shard) for _ in range(2)] if is_dst else []
                 else:       # one landing buffer per peer, sized for that peer's share
-                    self.landing = [[None if r == self.rank else b.alloc(B, *peer(r)) for r in range(self.world)]
-                                    for _ in range(2)] if is_dst else []
+                    self.landing_bufs = [[None if r == self.rank else b.alloc(B, *peer(r)) for r in range(self.world)]
+                                         for _ in range(2)] if is_dst else []
                     self.gathered = []
             else:
                 # one-stream form: at most F gathers outstanding, one slot and landing buffer each
@@ -615,23 +597,49 @@ class TileParallelRenderer:
                 if arith:
                     self.gathered = [b.alloc(self.world, *shard) for _ in range(self._slots)] if is_dst else []
                 else:
-                    self.landing = [[None if r == self.rank else b.alloc(*peer(r)) for r in range(self.world)]
-                                    for _ in range(self._slots)] if is_dst else []
+                    self.landing_bufs = [[None if r == self.rank else b.alloc(*peer(r)) for r in range(self.world)]
+                                         for _ in range(self._slots)] if is_dst else []
                     self.gathered = []
-            # the per-rank views torch.distributed.gather wants, made once (8 views cost ~8 us per frame)
-            self._glist = [list(g.unbind(0)) for g in self.gathered]
+            if not rot:
+                # the per-rank views torch.distributed.gather wants, made once (8 views cost ~8 us per frame)
+                self._glist = [list(g.unbind(0)) for g in self.gathered]
             if streams:
                 self._comm = self._make_stream_state(F, B)
 
     @property
     def framebuffer(self):
-        """(W, H, 3) image of the newest frame that has landed (rank dst; None elsewhere)."""
+        """(W, H, 3) image of the newest frame that has landed on this rank (None on a rank nothing lands on)."""
         return self._fbs[self._landed] if self._fbs else None
+
+    def landed_frames(self):
+        """[(frame number, (W, H, 3) image)] of the batch that landed last on this rank, oldest first; frame
+        numbers count ``render_frame`` calls from 0.  Valid in the caller's stream order until the next batch lands."""
+        return [(f, self._fbs[i]) for f, i in self._landed_frames]
+
+    def _batch_position(self, j: int) -> int:
+        """Where frame j of a batch sits in the batch's send buffer: rotating roots group the frames by destination
+        (frame j lands on rank j mod world: block j mod world, position j div world)."""
+        if self.landing == "rotate":
+            return (j % self.world) * self.per_dest + j // self.world
+        return j
+
+    def _lands_here(self, n_valid: int) -> int:
+        """How many of a batch's first n_valid frames land on this rank."""
+        if self.landing == "rotate":
+            return max(0, (n_valid - self.rank + self.world - 1) // self.world)
+        return n_valid if self._fbs else 0
+
+    def _note_landed(self, batch: int, n_land: int) -> None:
+        if n_land:
+            B = self.gather_batch
+            step, first = (self.world, self.rank) if self.landing == "rotate" else (1, 0)
+            self._landed_frames = [(batch * B + first + i * step, i) for i in range(n_land)]
+            self._landed = n_land - 1
 
     def _make_stream_state(self, F: int, B: int):
         """F render streams (handed to the C ABI as arguments, never made current) with a workspace
-        each; per frame slot a `traced` event, per batch slot a `sent` event (raw hipEvent_t handles:
-        the library records and waits on them inside rtgs_shard_frame / rtgs_frames_land)."""
+        each; per batch slot and render stream a `done` event, per batch slot a `sent` event (raw hipEvent_t
+        handles: the library records and waits on them inside rtgs_shard_frames / rtgs_frames_land)."""
         import ctypes
         b = self.backend
         nat = b.nat
@@ -652,10 +660,16 @@ class TileParallelRenderer:
         state = [(None, None)] * F
         if b.depth > nat.MAX_DEPTH:      # chained launches need per-pixel state, one pair per frame in flight
             state = [(b.alloc(b.width, b.height), b.alloc(b.width, b.height)) for _ in range(F)]
-        images = (ctypes.c_void_p * B)(*[fb.data_ptr() for fb in self._fbs]) if self._fbs else None
+        images = (ctypes.c_void_p * len(self._fbs))(*[fb.data_ptr() for fb in self._fbs]) if self._fbs else None
         self._counts_c = (ctypes.c_int32 * self.world)(*self.partition.counts)
-        return dict(render=[torch.cuda.Stream(device=b.device) for _ in range(F)], ws=ws, state=state,
-                    traced=[[event() for _ in range(B)] for _ in range(self._slots)],
+        render = [torch.cuda.Stream(device=b.device) for _ in range(F)]
+        done = [[event() for _ in range(F)] for _ in range(self._slots)]
+        return dict(render=render, ws=ws, state=state, done=done,
+                    done_c=[(ctypes.c_void_p * F)(*row) for row in done],
+                    streams_c=(ctypes.c_void_p * F)(*[rs.cuda_stream for rs in render]),
+                    ws_c=(ctypes.c_void_p * F)(*[w.data_ptr() for w in ws]),
+                    att_c=(ctypes.c_void_p * F)(*[nat.ptr(a) for a, _ in state]) if state[0][0] is not None else None,
+                    start_c=(ctypes.c_void_p * F)(*[nat.ptr(st) for _, st in state]) if state[0][0] is not None else None,
                     sent=[event() for _ in range(self._slots)], seen=[None] * F,
                     params=params, order=order, images=images, g=0, lib=lib)
 
@@ -665,7 +679,7 @@ class TileParallelRenderer:
         if cm is not None:
             for rs in cm["render"]:
                 rs.synchronize()
-            for ev in [e for row in cm["traced"] for e in row] + cm["sent"]:
+            for ev in [e for row in cm["done"] for e in row] + cm["sent"]:
                 cm["lib"].rtgs_event_destroy(ev)
 
     def __del__(self):
@@ -681,42 +695,83 @@ class TileParallelRenderer:
         return self.backend.scene.content_key()
 
     def render_frame(self) -> None:
-        """Queue one frame.  world == 1: straight into ``framebuffer``.  world > 1: trace this
-        rank's tiles into a slot of the compact-buffer ring on render stream f mod F; once the B
-        frames of a batch are queued, gather them (and, on rank dst, untile) on the caller's stream
-        while the render streams go on with the next frames: ``framebuffer`` is complete in the
-        caller's stream order.  (Without a HIP backend -- the CPU tests' stand-in -- or with
-        RTGS_RENDER_STREAM=0: one stream; start the gather, then complete the oldest outstanding
-        frame once F are in flight.)"""
+        """Queue one frame of the camera's current pose (``render_frames(count=1)``)."""
+        self.render_frames(count=1)
+
+    def render_frames(self, poses=None, count: int | None = None) -> None:
+        """Queue frames: one per pose of `poses` ((position, rotation) pairs or an (n, 7) array), or `count` frames of
+        the camera's current pose.  world == 1: straight into ``framebuffer``.  world > 1: this rank's tiles of frame
+        f are traced into the batch's compact buffer on render stream f mod F -- all frames of a call that belong to
+        one batch by ONE library call (``rtgs_shard_frames``) -- and once the B frames of a batch are queued it is
+        exchanged and landed on the caller's stream while the render streams go on with the next frames:
+        ``framebuffer`` / ``landed_frames()`` are complete in the caller's stream order.  (Without a HIP backend --
+        the CPU tests' stand-in -- or with RTGS_RENDER_STREAM=0: one stream, frame by frame.)"""
+        b = self.backend
+        if poses is not None:
+            poses = _pose_rows(poses)
+        n = len(poses) if poses is not None else int(1 if count is None else count)
+        if n <= 0:
+            return
+        if self._comm is None:
+            cam = getattr(b, "camera", None)
+            for i in range(n):
+                if poses is not None and cam is not None:
+                    from .utils.types import vec3, vec4
+                    cam.position, cam.rotation = vec3(poses[i, :3]), vec4(poses[i, 3:])
+                self._render_one_serial()
+            return
+        import ctypes
+        cm, nat = self._comm, b.nat
+        B, F = self.gather_batch, self.frames_in_flight
+        key = self._scene_key()
+        stale = [s for s in range(F) if cm["seen"][s] != key]
+        if stale:
+            # scene uploads / edits queued on the caller's stream (rare: torch objects are fine here)
+            cur_s = nat.current_stream(b.device.index)
+            for s in stale:
+                cm["render"][s].wait_stream(cur_s)
+                cm["seen"][s] = key
+        cur = nat.stream()                     # raw handle of the caller's stream
+        cams, total = b.camera_array(poses, n)
+        done = 0
+        while done < n:
+            f = self._frame
+            q, j0 = divmod(f, B)
+            m = min(n - done, B - j0)
+            slot = q % self._slots
+            out = self.compact[slot]
+            base, stride = out.data_ptr(), out.stride(0) * 4
+            outs = (ctypes.c_void_p * m)(*[(base + self._batch_position(j0 + i) * stride) if self.local_tiles else None
+                                           for i in range(m)])
+            nat.check(cm["lib"].rtgs_shard_frames(
+                b.scene_native(), cams.ctypes.data + done * cams.itemsize, m, cm["params"], outs, cm["att_c"], cm["start_c"],
+                cm["ws_c"], cm["ws"][0].numel(), cm["streams_c"], F, f % F, cm["sent"][slot], cm["done_c"][slot], cur, 1),
+                "rtgs_shard_frames")
+            self._frame += m
+            done += m
+            if j0 + m == B:
+                self._exchange(slot, B, cur, q)
+
+    def _render_one_serial(self) -> None:
+        """One frame on the caller's stream (no render streams: the CPU tests' stand-in backend, RTGS_RENDER_STREAM=0)."""
         b = self.backend
         if self.world == 1:
             b.render(self._fbs[0], 0, 1, compact=False)
             return
         f = self._frame
         self._frame += 1
-        if self._comm is not None:
-            cm, nat = self._comm, b.nat
+        if self.landing == "rotate":
             B = self.gather_batch
             q, j = divmod(f, B)
             slot = q % self._slots
-            s = f % self.frames_in_flight
-            rs = cm["render"][s]
-            key = self._scene_key()
-            if cm["seen"][s] != key:
-                # scene uploads / edits queued on the caller's stream (rare: torch objects are fine here)
-                rs.wait_stream(nat.current_stream(b.device.index))
-                cm["seen"][s] = key
-            cur = nat.stream()                     # raw handle of the caller's stream
-            ws = cm["ws"][s]
-            att, start = cm["state"][s]
-            out = self.compact[slot]
-            nat.check(cm["lib"].rtgs_shard_frame(
-                b.scene_native(), b.camera_native(), cm["params"],
-                out.data_ptr() + j * out.stride(0) * 4, nat.ptr(att), nat.ptr(start),
-                ws.data_ptr(), ws.numel(), rs.cuda_stream, cm["sent"][slot], cm["traced"][slot][j], cur, 1),
-                "rtgs_shard_frame")
+            if self.local_tiles:
+                out = self.compact[slot][self._batch_position(j)]
+                if self._shard is not None:
+                    b.render(out, self.rank, self.world, compact=True, shard=self._shard)
+                else:
+                    b.render(out, self.rank, self.world, compact=True)
             if j == B - 1:
-                self._exchange(slot, B, cur)
+                self._exchange_rotate_serial(slot, B, q)
             return
         k = f % self._slots
         if self.local_tiles:
@@ -728,7 +783,7 @@ class TileParallelRenderer:
             work = self._gather(self.compact[k], gather_list=self._glist[k] if self._glist else None, dst=self.dst,
                                 group=self.group, async_op=True)
         else:
-            work = self._p2p(self.compact[k], self.landing[k] if self._fbs else None)
+            work = self._p2p(self.compact[k], self.landing_bufs[k] if self._fbs else None)
         self._pending.append((work, k))
         while len(self._pending) >= max(self.frames_in_flight, 2):
             self._complete(self._pending.pop(0))
@@ -755,36 +810,77 @@ class TileParallelRenderer:
             ops = [dist.P2POp(dist.isend, mine, self.dst, self.group)]
         return dist.batch_isend_irecv(ops) if ops else []
 
-    def _exchange(self, slot: int, n_frames: int, cur: int) -> None:
-        """Gather batch slot `slot` on the caller's stream (it already waits for the batch's traces)
-        and land its first n_frames frames."""
+    def _all_to_all_batch(self, slot: int, g: int) -> None:
+        """The rotating roots' exchange of batch slot `slot`: block d of this rank's send buffer (its shards of the
+        batch's frames d, d + world, ...) goes to rank d; block s of the landing buffer comes from rank s."""
+        send, recv = self.compact[slot], self.gathered[g]
+        if self.partition.arithmetic:
+            self._a2a(recv, send, None, None, group=self.group)
+        else:
+            self._a2a(recv[:sum(self._split_out)], send.reshape(-1), self._split_out, self._split_in, group=self.group)
+
+    def _exchange(self, slot: int, n_frames: int, cur: int, batch: int) -> None:
+        """Exchange batch slot `slot` (batch number `batch`) on the caller's stream (it already waits for the batch's
+        traces) and land its first n_frames frames."""
+        import ctypes
         cm, b = self._comm, self.backend
         g = cm["g"]
         cm["g"] = g ^ 1
+        land = self._lands_here(n_frames)
+        N, k = self.world, self.per_dest
+        if self.landing == "rotate":
+            self._all_to_all_batch(slot, g)
+            if self.partition.arithmetic:
+                b.nat.check(cm["lib"].rtgs_frames_land(
+                    self.gathered[g].data_ptr(), N, self.tiles_per_rank, k, land, b.width, b.height, cm["images"], cur,
+                    cm["sent"][slot]), "rtgs_frames_land")
+            else:
+                base = self.gathered[g].data_ptr()
+                bufs = (ctypes.c_void_p * N)(*[(base + 4 * self._recv_off[r]) if self.partition.counts[r] else None
+                                               for r in range(N)])
+                b.nat.check(cm["lib"].rtgs_frames_land_map(
+                    bufs, self._counts_c, N, b.nat.ptr(self._tile_map), k, land, b.width, b.height, cm["images"], cur,
+                    cm["sent"][slot]), "rtgs_frames_land_map")
+            self._note_landed(batch, land)
+            return
         if not self.partition.arithmetic:
-            import ctypes
-            for w in self._p2p(self.compact[slot], self.landing[g] if self._fbs else None):
+            for w in self._p2p(self.compact[slot], self.landing_bufs[g] if self._fbs else None):
                 w.wait()                      # (NCCL: orders the caller's stream behind the transfer, no host wait)
-            land = n_frames if self._fbs else 0
             bufs = None
             if land:
-                bufs = (ctypes.c_void_p * self.world)(*[
-                    (self.compact[slot] if r == self.rank else self.landing[g][r]).data_ptr() if self.partition.counts[r] else None
-                    for r in range(self.world)])
+                bufs = (ctypes.c_void_p * N)(*[
+                    (self.compact[slot] if r == self.rank else self.landing_bufs[g][r]).data_ptr() if self.partition.counts[r] else None
+                    for r in range(N)])
             b.nat.check(cm["lib"].rtgs_frames_land_map(
-                bufs, self._counts_c, self.world, b.nat.ptr(self._tile_map), self.gather_batch, land, b.width, b.height,
+                bufs, self._counts_c, N, b.nat.ptr(self._tile_map), self.gather_batch, land, b.width, b.height,
                 cm["images"], cur, cm["sent"][slot]), "rtgs_frames_land_map")
-            if land:
-                self._landed = land - 1
+            self._note_landed(batch, land)
             return
         self._gather(self.compact[slot], gather_list=self._glist[g] if self._glist else None, dst=self.dst,
                      group=self.group, async_op=False)
-        land = n_frames if self._fbs else 0
         b.nat.check(cm["lib"].rtgs_frames_land(
-            self.gathered[g].data_ptr() if self.gathered else None, self.world, self.tiles_per_rank,
+            self.gathered[g].data_ptr() if self.gathered else None, N, self.tiles_per_rank,
             self.gather_batch, land, b.width, b.height, cm["images"], cur, cm["sent"][slot]), "rtgs_frames_land")
-        if land:
-            self._landed = land - 1
+        self._note_landed(batch, land)
+
+    def _exchange_rotate_serial(self, slot: int, n_frames: int, batch: int) -> None:
+        """The rotating roots' exchange and landing without render streams (stand-in backend, RTGS_RENDER_STREAM=0)."""
+        b = self.backend
+        g = batch & 1
+        self._all_to_all_batch(slot, g)
+        land = self._lands_here(n_frames)
+        N, k, T = self.world, self.per_dest, self.TILE
+        for i in range(land):
+            if self.partition.arithmetic:
+                # gathered[g] = [source][k][tiles][T][T][3]: frame i's shards are [:, i]
+                view = self.gathered[g].reshape(N, k, self.tiles_per_rank, T, T, 3)[:, i]
+                b.untile(view.contiguous() if not view.is_contiguous() else view, N, self.tiles_per_rank, self._fbs[i])
+            else:
+                flat, cnt = self.gathered[g], self.partition.counts
+                bufs = [flat[self._recv_off[r]:self._recv_off[r] + self._split_out[r]].reshape(k, cnt[r], T, T, 3)[i]
+                        if cnt[r] else None for r in range(N)]
+                b.untile_map(bufs, cnt, self._tile_map, self._fbs[i])
+        self._note_landed(batch, land)
 
     def _complete(self, pending) -> None:
         work, k = pending
@@ -792,7 +888,7 @@ class TileParallelRenderer:
             for w in work:
                 w.wait()
             if self._fbs:
-                bufs = [(self.compact[k] if r == self.rank else self.landing[k][r]) if self.partition.counts[r] else None
+                bufs = [(self.compact[k] if r == self.rank else self.landing_bufs[k][r]) if self.partition.counts[r] else None
                         for r in range(self.world)]
                 self.backend.untile_map(bufs, self.partition.counts, self._tile_map, self._fbs[0])
             return
@@ -801,21 +897,25 @@ class TileParallelRenderer:
             self.backend.untile(self.gathered[k], self.world, self.tiles_per_rank, self._fbs[0])
 
     def finish(self) -> None:
-        """Drain the pipeline: after this ``framebuffer`` on rank dst holds the last frame (in the
+        """Drain the pipeline: after this ``framebuffer`` (``landed_frames()``) holds the last frame(s) (in the
         caller's stream order) and the render streams have nothing queued that the caller's stream
         has not waited for -- buffers may be released, the scene re-committed.  A partial batch is
         exchanged as it is (every rank calls finish() after the same number of frames)."""
         while self._pending:
             self._complete(self._pending.pop(0))
+        B = self.gather_batch
+        q, j = divmod(self._frame, B)
         if self._comm is not None:
-            b, B = self.backend, self.gather_batch
-            q, j = divmod(self._frame, B)
+            b = self.backend
             if j:
-                self._exchange(q % self._slots, j, b.nat.stream())
+                self._exchange(q % self._slots, j, b.nat.stream(), q)
                 self._frame = (q + 1) * B          # the next frame opens a new batch
             cur = b.nat.current_stream(b.device.index)
             for rs in self._comm["render"]:
                 cur.wait_stream(rs)
+        elif self.world > 1 and self.landing == "rotate" and j:
+            self._exchange_rotate_serial(q % self._slots, j, q)
+            self._frame = (q + 1) * B
 
     # ---- pieces, for measurement -----------------------------------------------------------
     def project_only(self) -> None:
@@ -827,4 +927,7 @@ class TileParallelRenderer:
         if self.world == 1:
             b.trace(self.framebuffer, 0, 1, compact=False, projected=True)
         elif self.local_tiles:
-            b.trace(self.compact[0], self.rank, self.world, compact=True, projected=True, shard=self._shard)
+            out = self.compact[0]
+            if out.dim() == 5:           # a batch buffer: its first frame
+                out = out[0]
+            b.trace(out, self.rank, self.world, compact=True, projected=True, shard=self._shard)

@@ -48,6 +48,8 @@ class RayTracer:
         self._lists = None           # device buffer, rtgs_peel_list_bytes(W, H)
         self._lists_for = None       # (scene, geometry, pose, focal) the lists were traversed for
         self._list_peels = None      # peels of the CURRENT sample composited from the lists; None = not in step with them
+        self._state_peels = 0        # peels the ray field's deferred .start update has to account for (rtgs_peel_start)
+        self._sample_pose = None     # (position, rotation) the listed sample in progress was started from
 
     @property
     def attenuation_buf(self) -> torch.Tensor:

@@ -26,25 +26,33 @@ def _run(args, env=None, timeout=900):
     return out, (json.loads(lines[-1]) if lines else None)
 
 
-@pytest.mark.parametrize("env", [{}, {"RTGS_GATHER_BATCH": "2", "RTGS_FRAMES_IN_FLIGHT": "3"}])
-def test_bare_bench_with_two_ranks_starts_them_itself_and_verifies(env):
+@pytest.mark.parametrize("extra,env", [([], {}), (["--gather-batch", "4"], {"RTGS_FRAMES_IN_FLIGHT": "3"})])
+def test_bare_bench_with_two_ranks_starts_them_itself_and_verifies(extra, env):
     out, line = _run(["--gpus", "2", "--backend", "gloo", "--same-device", "--steps", "6", "--warmup", "2",
-                      "--config", "c2"], env)
+                      "--config", "c2", *extra], env)
     assert out.returncode == 0, out.stderr[-2000:]
     assert line is not None and line["n_gpus"] == 2 and line["verified"] is True
-    assert line["value"] > 0 and line["steps"] == 6
+    assert line["value"] > 0 and line["steps"] == 6 and line["timed_s"] >= 1.0
     pr = line["per_rank"]
     assert len(pr["trace_ms"]) == 2 and pr["trace_ms_min"] <= pr["trace_ms_max"]
     assert sum(pr["local_tiles"]) == -(-800 // 16) * -(-600 // 16)
     assert "gloo" in line["config"]["parallelism"]            # a rehearsal must say so
-    # both tile deals ran and verified: the equal round-robin one (dist.gather) and the one calibrated on this
-    # machine (unequal shares, explicit tile lists, point to point)
+    # every deal ran and verified: round 4's two -- the equal round-robin one (dist.gather per frame) and the one
+    # calibrated on this machine (unequal shares, explicit tile lists, point to point) -- and round 5's two: B frames
+    # per library call and collective, landing on rank 0 and on ROTATING roots (one all_to_all per batch)
+    gb = extra[1] if extra else "8"
     parts = line["secondary"]["partitions"]
-    assert set(parts) == {"equal", "auto"} and all(p is not None and p["verified"] is True for p in parts.values())
-    assert parts["equal"]["deal"] == "round-robin" and line["secondary"]["partition_reported"] in parts
-    cal = parts["auto"]["calibration"]
+    assert set(parts) == {"equal/root/B1", "auto/root/B1", f"equal/root/B{gb}", f"equal/rotate/B{gb}"}
+    assert all(p is not None and p["verified"] is True for p in parts.values())
+    assert parts["equal/root/B1"]["deal"] == "round-robin" and line["secondary"]["partition_reported"] in parts
+    assert parts[f"equal/rotate/B{gb}"]["landing"] == "rotate" and parts[f"equal/rotate/B{gb}"]["frames_per_collective"] == int(gb)
+    cal = parts["auto/root/B1"]["calibration"]
     assert cal["t_shard_ms"] > 0 and cal["t_frame_ms"] > cal["t_shard_ms"] * 0.5 and cal["t_exchange_ms"] > 0
-    assert abs(sum(parts["auto"]["shares"]) - 1) < 1e-6 and parts["auto"]["shares"][0] >= 0.5 - 1 / 64
+    assert abs(sum(parts["auto/root/B1"]["shares"]) - 1) < 1e-6 and parts["auto/root/B1"]["shares"][0] >= 0.5 - 1 / 64
+    # a deal that leaves ranks without tiles (the one-GPU rehearsal's calibration keeps everything on rank 0) never
+    # carries the headline: the line then says how many ranks rendered
+    rep = parts[line["secondary"]["partition_reported"]]
+    assert rep["rendering_ranks"] == 2
 
 
 def test_explicit_unequal_shares_cross_the_point_to_point_exchange():
@@ -66,19 +74,27 @@ def test_the_sector_deal_with_its_region_cull_verifies_through_the_real_exchange
     assert line["per_rank"]["local_tiles"] == [950, 950]
 
 
-def test_a_deal_that_hangs_does_not_take_the_finished_deals_number_with_it():
+@pytest.mark.parametrize("hook", ["RTGS_BENCH_TEST_HANG", "RTGS_BENCH_TEST_RAISE"])
+def test_a_deal_that_hangs_or_raises_on_one_rank_does_not_take_the_finished_deals_number_with_it(hook):
     # the unequal deals' point-to-point exchange has never met RCCL: if the second deal never ends (test hook: the last
-    # rank sleeps instead of running it), every rank's watchdog fires, rank 0 prints the line of the deal that did
-    # finish and verify, and the job ends with status 0 -- in the torchrun form too, where no launcher of ours watches
+    # rank sleeps instead of running it) -- or RAISES on the last rank only, which then waits in the deal's collective
+    # outcome while rank 0 is still inside the deal's own collectives -- every rank's watchdog fires, rank 0
+    # prints the line of the deal that did finish and verify, and EVERY rank ends with status 0 -- in the torchrun form
+    # too, where no launcher of ours watches
     out, line = _run(["--gpus", "2", "--backend", "gloo", "--same-device", "--steps", "4", "--warmup", "1",
-                      "--config", "c2", "--mode-timeout", "20"], {"RTGS_BENCH_TEST_HANG": "auto"}, timeout=600)
+                      "--config", "c2", "--mode-timeout", "20", "--landing", "root", "--gather-batch", "1"],
+                     {hook: "auto/root/B1"}, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert len([l for l in out.stdout.splitlines() if l.startswith("{")]) == 1
     assert line["verified"] is True and line["n_gpus"] == 2
     sec = line["secondary"]
-    assert sec["partition_reported"] == "equal" and sec["partition_abandoned"]["partition"] == "auto"
-    assert sec["partitions"]["equal"]["verified"] is True and "auto" not in sec["partitions"]
-    assert "given up" in out.stderr
+    assert sec["partition_reported"] == "equal/root/B1"
+    assert sec["partitions"]["equal/root/B1"]["verified"] is True
+    if "partition_abandoned" in sec:          # (the watchdog's line; a raise that every rank saw in step just drops the deal)
+        assert sec["partition_abandoned"]["partition"] == "auto/root/B1" and "given up" in out.stderr
+        assert "auto/root/B1" not in sec["partitions"]
+    else:
+        assert hook.endswith("RAISE") and sec["partitions"]["auto/root/B1"] is None
 
 
 def test_launched_by_torch_distributed_run_it_is_a_rank_as_before():
@@ -96,7 +112,8 @@ def test_launched_by_torch_distributed_run_it_is_a_rank_as_before():
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                     # ONE line, from rank 0
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["verified"] is True and set(line["secondary"]["partitions"]) == {"equal"}
+    assert line["n_gpus"] == 2 and line["verified"] is True
+    assert set(line["secondary"]["partitions"]) == {"equal/root/B1", "equal/root/B8", "equal/rotate/B8"}
 
 
 def test_more_ranks_than_devices_is_refused_with_a_nonzero_status():
@@ -108,8 +125,8 @@ def test_more_ranks_than_devices_is_refused_with_a_nonzero_status():
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
-@pytest.mark.parametrize("env", [{}, {"RTGS_GATHER_BATCH": "2"}])
-def test_two_ranks_over_rccl(env):
-    out, line = _run(["--gpus", "2", "--steps", "20", "--warmup", "5", "--config", "c2"], env)
+@pytest.mark.parametrize("extra", [[], ["--gather-batch", "2"]])
+def test_two_ranks_over_rccl(extra):
+    out, line = _run(["--gpus", "2", "--steps", "20", "--warmup", "5", "--config", "c2", *extra])
     assert out.returncode == 0, out.stderr[-2000:]
     assert line["verified"] is True and "RCCL" in line["config"]["parallelism"]

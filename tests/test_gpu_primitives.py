@@ -102,6 +102,26 @@ def test_gaussian_hit_of_the_default_gaussian():
     assert math.isinf(miss.x) and math.isinf(miss.y)
 
 
+def test_bounding_box_is_the_box_of_the_six_axis_end_points():
+    # gaussian.py:104-138: min / max over position +- R S (3 e_k) -- analytic for the identity rotation (+- 3 s), a
+    # quarter turn about z (x and y extents swap), and against the oracle's restatement for random Gaussians
+    g = new_gaussian(vec3(1, 2, 3), vec4(0, 0, 0, 1), vec3(0.5, 1.0, 2.0))
+    b = g.bounding_box()
+    assert np.allclose(b.p_min, (1 - 1.5, 2 - 3.0, 3 - 6.0), atol=1e-6) and np.allclose(b.p_max, (2.5, 5.0, 9.0), atol=1e-6)
+    assert np.allclose(b.get_centroid(), (1, 2, 3), atol=1e-6) and np.allclose(b.size(), (3, 6, 12), atol=1e-6)
+    s2 = math.sqrt(0.5)
+    b = new_gaussian(vec3(0), vec4(0, 0, s2, s2), vec3(0.5, 1.0, 2.0)).bounding_box()
+    assert np.allclose(b.p_max, (3.0, 1.5, 6.0), atol=1e-5) and np.allclose(b.p_min, (-3.0, -1.5, -6.0), atol=1e-5)
+    rng = np.random.default_rng(11)
+    for _ in range(8):
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        pos, sc = rng.normal(size=3), rng.uniform(0.05, 2.0, 3)
+        b = new_gaussian(pos, q, sc).bounding_box()
+        lo, hi = ref.gaussian_bounding_box(np.float32(pos), np.float32(q), np.float32(sc))
+        assert np.allclose(b.p_min, lo, atol=2e-6 * (1 + np.abs(lo).max())) and np.allclose(b.p_max, hi, atol=2e-6 * (1 + np.abs(hi).max()))
+
+
 def test_cov_hit_eval_match_the_oracle():
     rng = np.random.default_rng(7)
     for _ in range(8):

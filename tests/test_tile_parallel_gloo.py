@@ -110,6 +110,68 @@ def _worker(rank, world, port, frames, q, in_flight=2, shares=None):
         dist.destroy_process_group()
 
 
+def _rotate_worker(rank, world, port, frames, q, batch, shares, poses_per_call):
+    """landing="rotate": frame f lands on rank f mod world, one all_to_all_single per batch of B frames; EVERY landed
+    frame is checked on the rank that holds it, after every batch and after the partial last one."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        image = _oracle_image()
+        from rtgs.parallel import TileParallelRenderer
+        be = OracleBackend(image)
+        r = TileParallelRenderer(backend=be, rank=rank, world=world, partition=shares, landing="rotate", gather_batch=batch)
+        B = r.gather_batch
+        assert B % world == 0 and B >= batch and r.per_dest == B // world and len(r._fbs) == r.per_dest
+        seen = {}
+
+        def check():
+            for f, img in r.landed_frames():
+                assert f % world == rank
+                if f not in seen:            # (a batch that lands nothing here leaves the previous one's frames named)
+                    seen[f] = float((img - image * float(f + 1)).abs().max())
+
+        done = 0
+        while done < frames:
+            n = min(poses_per_call, frames - done)
+            before = done // B
+            r.render_frames(count=n)
+            done += n
+            if done // B != before:
+                check()
+            # an empty share renders nothing: keep the stand-in's frame counter in step with the peers'
+            be.frame = done
+        r.finish()
+        if frames % B:
+            check()
+        q.put((rank, seen))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,frames,batch,shares,per_call", [
+    (2, 4, 2, None, 1), (2, 7, 4, None, 3), (3, 10, 3, None, 1), (3, 7, 6, None, 7), (4, 9, 4, None, 2),
+    (2, 5, 2, (3, 1), 1), (3, 8, 3, (5, 0, 1), 2), (3, 4, 6, "wedges", 4), (4, 6, 8, (1, 2, 0, 4), 6)])
+def test_rotating_roots_land_every_frame_on_its_rank(world, frames, batch, shares, per_call):
+    # VERDICT r4 #1: world-2/3/4, equal / unequal / empty shares, several frames per call, a partial last batch:
+    # every frame of the LAST complete-or-partial batch and of every batch before it must be bit-exact on rank f mod world
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    mp.spawn(_rotate_worker, args=(world, _free_port(), frames, q, batch, shares, per_call), nprocs=world, join=True)
+    got = dict(q.get(timeout=30) for _ in range(world))
+    B = (batch + world - 1) // world * world
+    landed = {}
+    for rank, seen in got.items():
+        for f, err in seen.items():
+            assert f % world == rank and err == 0.0, (rank, f, err)
+            landed[f] = rank
+    # batches are only looked at when a call crosses their end (the ring of k framebuffers is overwritten by the next
+    # batch): the last batch -- complete or partial -- is always seen in full
+    last = range((frames - 1) // B * B, frames)
+    assert set(last) <= set(landed), (sorted(landed), list(last))
+    if per_call <= B:                # (a call then ends at most one batch: every batch was looked at)
+        assert set(landed) == set(range(frames))
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

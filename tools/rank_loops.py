@@ -1,11 +1,13 @@
-"""EVERY rank's tile-parallel frame loop on ONE GPU, one after the other (VERDICT r3 #2c): for N = 2, 4, 8 and the
-equal and the link-aware deals, each rank's loop (project + trace on F render streams, event chain, the destination's
-scatter; the exchange itself stubbed out) in microseconds per frame, the maximum over the ranks, and -- labelled as a
-PROJECTION -- the frame time with one peer's bytes crossing an xGMI link at an assumed rate.  The shares of the
-link-aware deal come from rtgs.parallel.balanced_share with the exchange time that rate implies (on hardware the
-renderer measures it: TileParallelRenderer(partition="auto")).
+"""EVERY rank's tile-parallel frame loop on ONE GPU, one after the other (VERDICT r3 #2c, r4 #1): for N = 2, 4, 8, for
+the single root (every frame lands on rank 0: one gather per batch) and for ROTATING roots (frame f lands on rank
+f mod N: one all_to_all per batch), each rank's loop -- rtgs_shard_frames (project + trace of B frames over F render
+streams), the event chain, the landing scatter of the frames that land on that rank; the exchange itself stubbed out --
+in microseconds per frame, the maximum over the ranks, and -- labelled as a PROJECTION -- the frame time with the
+bytes a link has to carry per frame at an assumed rate (root: one 1/N shard per frame into rank 0 over each link;
+rotate: one 1/N shard per N frames over each link).
 
-usage: python tools/rank_loops.py [cfg ...]    env: WORLDS="2 4 8"  LINK_GBS="50 64 77"  F=2  DEALS=wedges (also the sector deal)"""
+usage: python tools/rank_loops.py [cfg ...]   env: WORLDS="2 4 8"  LINK_GBS="50 64 77"  F="2 3"  B="1 8"  DEALS="equal wedges weighted"
+"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "rt-gaussian-splat-renderer_amd"), ROOT]
@@ -13,23 +15,33 @@ import torch
 import rtgs
 from rtgs import synthetic
 from rtgs import _native as nat
-from rtgs.parallel import Partition, TileParallelRenderer, _no_gather, balanced_share, tiles_of
+from rtgs.parallel import Partition, TileParallelRenderer, _no_all_to_all, _no_gather, balanced_share, tiles_of
 
 torch.cuda.set_device(0)
-F = int(os.environ.get("F", "2"))
+Fs = [int(v) for v in os.environ.get("F", "2 3").split()]
+Bs = [int(v) for v in os.environ.get("B", "1 8").split()]
 worlds = [int(v) for v in os.environ.get("WORLDS", "2 4 8").split()]
 links = [float(v) for v in os.environ.get("LINK_GBS", "50 64 77").split()]
+deals = os.environ.get("DEALS", "equal").split()
 
 
 def loop_us(r, n):
-    for _ in range(20):
-        r.render_frame()
+    r.render_frames(count=24)
     r.finish(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(n):
-        r.render_frame()
+    r.render_frames(count=n)
     r.finish(); torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n * 1e6
+
+
+def host_us(r, n):
+    """Host time of queueing n frames (the GPU drains afterwards, untimed)."""
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    r.render_frames(count=n)
+    dt = time.perf_counter() - t0
+    r.finish(); torch.cuda.synchronize()
+    return dt / n * 1e6
 
 
 for name in (sys.argv[1:] or ["c3", "c5"]):
@@ -37,37 +49,37 @@ for name in (sys.argv[1:] or ["c3", "c5"]):
     arrays = synthetic.make_config_scene(cfg); cam = synthetic.bench_camera(cfg.width, cfg.height)
     scene = rtgs.Scene.from_arrays(**arrays)
     camera = rtgs.Camera(cam["position"], cam["rotation"], (cfg.width, cfg.height), (cam["fx"], cam["fy"]))
-    n = 300 if name != "c5" else 100
+    n = 480 if name != "c5" else 96
     total = tiles_of(cfg.width, cfg.height, nat.tile_size())
     frame_bytes = cfg.width * cfg.height * 12
     one = TileParallelRenderer(scene, camera, depth=cfg.depth, rank=0, world=1)
     t_frame = loop_us(one, n)
-    print(f"== {name}: single-GPU frame loop {t_frame:.1f} us ({cfg.width}x{cfg.height}, {frame_bytes / 1e6:.1f} MB of pixels), {F} frames in flight per rank")
+    print(f"== {name}: single-GPU frame loop {t_frame:.1f} us ({cfg.width}x{cfg.height}, {frame_bytes / 1e6:.1f} MB of pixels)", flush=True)
     for world in worlds:
-        eq = TileParallelRenderer(scene, camera, depth=cfg.depth, rank=0, world=world, gather_fn=_no_gather, frames_in_flight=F)
-        t_shard = loop_us(eq, n); eq.close()
-        deals = [("equal", None, None)]
-        if "wedges" in os.environ.get("DEALS", ""):
-            deals.append(("wedges (one compact sector per rank)", "wedges", None))
-        for gbs in links:
-            t_x = frame_bytes / world / (gbs * 1e3)           # us for one 1/N shard over one link
-            x = balanced_share(world, t_shard, t_frame, t_x)
-            if x > 1.02 / world:
-                sh = [(1 - x) / (world - 1)] * world; sh[0] = x
-                deals.append((f"weighted for {gbs:.0f} GB/s (x = {x:.2f})", sh, gbs))
-        for label, shares, gbs in deals:
-            part = (Partition.round_robin(total, world) if shares is None else
-                    Partition.wedges(cfg.width, cfg.height, nat.tile_size(), world) if isinstance(shares, str) else
-                    Partition.weighted(total, shares))
-            per = []
-            for rank in range(world):
-                r = TileParallelRenderer(scene, camera, depth=cfg.depth, rank=rank, world=world, gather_fn=_no_gather,
-                                         p2p_fn=lambda mine, landing: [], partition=part, frames_in_flight=F)
-                per.append(loop_us(r, n)); r.close()
-            worst = max(per)
-            peer_bytes = max(part.counts[1:]) * 256 * 12
-            proj = " | ".join(f"{g:.0f} GB/s: link {peer_bytes / (g * 1e3):.0f} us -> frame {max(worst, peer_bytes / (g * 1e3)):.0f} us = {t_frame / max(worst, peer_bytes / (g * 1e3)):.2f}x"
-                             for g in ([gbs] if gbs else links))
-            print(f"{name} N={world} {label}: deal {part.name}; rank loops us " + " ".join(f"{v:.0f}" for v in per) +
-                  f"; max {worst:.0f} (rank {per.index(worst)}); PROJECTION {proj}")
+        parts = []
+        if "equal" in deals:
+            parts.append(("equal", Partition.round_robin(total, world)))
+        if "wedges" in deals:
+            parts.append(("wedges", Partition.wedges(cfg.width, cfg.height, nat.tile_size(), world)))
+        for dname, part in parts:
+            for landing in ("root", "rotate"):
+                for B in Bs:
+                    if landing == "rotate" and B < world:
+                        continue
+                    for F in Fs:
+                        per, host = [], []
+                        for rank in range(world):
+                            r = TileParallelRenderer(scene, camera, depth=cfg.depth, rank=rank, world=world, gather_fn=_no_gather,
+                                                     p2p_fn=lambda mine, landing: [], a2a_fn=_no_all_to_all, partition=part,
+                                                     frames_in_flight=F, gather_batch=B, landing=landing)
+                            per.append(loop_us(r, n)); host.append(host_us(r, n)); r.close()
+                            Beff = r.gather_batch
+                        worst = max(per)
+                        shard = max(part.counts) * 256 * 12
+                        link_bytes = shard if landing == "root" else shard / world       # per frame over one link
+                        proj = " | ".join(f"{g:.0f} GB/s: link {link_bytes / (g * 1e3):.0f} us -> frame {max(worst, link_bytes / (g * 1e3)):.0f} us = "
+                                          f"{t_frame / max(worst, link_bytes / (g * 1e3)):.2f}x" for g in links)
+                        print(f"{name} N={world} {dname} landing={landing} B={Beff} F={F}: rank loops us " + " ".join(f"{v:.0f}" for v in per) +
+                              f"; max {worst:.0f} (rank {per.index(worst)}) = {t_frame / worst:.2f}x without the link; host us/frame " +
+                              " ".join(f"{v:.0f}" for v in host) + f"; PROJECTION {proj}", flush=True)
     del scene
