@@ -407,7 +407,7 @@ def rank_main(args) -> int:
             if renderer.landing == "rotate":
                 last0 = first + (len(seq) - 1) // B * B    # the last batch of the sequence, complete or partial
                 mine = [(f, img) for f, img in renderer.landed_frames() if last0 <= f < first + len(seq)]
-                want_n = len([f for f in range(last0, first + len(seq)) if f % world == rank])
+                want_n = len([f for f in range(last0, first + len(seq)) if renderer.destination(f) == rank])
                 if len(mine) != want_n:
                     held.append((None, None))
                 held += [(seq[f - first], img.clone()) for f, img in mine]
@@ -579,7 +579,7 @@ def rank_main(args) -> int:
             f"Mrays/s at {cfg.width}x{cfg.height}, {cfg.n} Gaussians; achieved HBM GB/s vs peak"
         comm = ""
         if world > 1:
-            what = "all_to_all to rotating roots (frame f lands on rank f mod N)" if best["landing"] == "rotate" else "gather to rank 0"
+            what = "all_to_all to rotating roots (every rank lands 1/N of the frames)" if best["landing"] == "rotate" else "gather to rank 0"
             comm = f" + RCCL {what}" if args.backend == "nccl" else f" + {args.backend} {what} (rehearsal, not RCCL)"
             comm += (f", {renderer.frames_in_flight} frames in flight per rank, {renderer.gather_batch} frames per library "
                      f"call and collective, tile deal: {best['partition']}")

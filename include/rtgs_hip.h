@@ -95,6 +95,13 @@ typedef struct RtgsCamera {
 #define RTGS_TRACE_REGION 64u     /* the shard's tiles all lie inside RtgsTraceParams.region: the projection this call
                                      runs skips the Gaussians that cannot reach it (same pixels) */
 
+/* scheduling only, same pixels: force / forbid the per-frame slab bins (k_bin) for this call's own projection.  By
+ * default a shard below a sixth of the frame scans for itself -- right for ONE such launch on an idle chip (k_bin's
+ * latency is longer than what its lists save a lone resident round of tiles), wrong once several frames' shards are in
+ * flight and the chip is throughput-bound (rtgs.parallel with frames_in_flight >= 2 sets BINS_ON) */
+#define RTGS_TRACE_BINS_ON 128u
+#define RTGS_TRACE_BINS_OFF 256u
+
 typedef struct RtgsTraceParams {
   int32_t depth;        /* peels performed by this call, >= 1.  Above RTGS_MAX_DEPTH the call  */
                         /* is a chain of ceil(depth/16) launches through attenuation_buf and  */
@@ -154,6 +161,11 @@ int rtgs_pose_pack(const RtgsCamera* cam, void* host_out);
  * lists at 1080p, 33 MB at 4K).  The calls check against the frame's figure. */
 size_t rtgs_workspace_bytes(int32_t n);
 size_t rtgs_workspace_bytes_frame(int32_t n, int32_t width, int32_t height);
+/* (ABI v7) A workspace for `frames` consecutive frames of one render stream of rtgs_shard_frames, which then renders
+ * them in ONE launch per kernel (grid.y = frames, at most rtgs_max_frames_per_launch() = 8): per frame the workspace
+ * above plus a pose block, rounded to 256 B.  frames = 1 is rtgs_workspace_bytes_frame. */
+size_t rtgs_workspace_bytes_frames(int32_t n, int32_t width, int32_t height, int32_t frames);
+int32_t rtgs_max_frames_per_launch(void);
 
 /* Macro-tile edge the library was built with, the number of macro-tiles of a W x H image, and
  * how many of them a shard owns. */
@@ -271,7 +283,12 @@ int rtgs_shard_frame(const RtgsScene* scene, const RtgsCamera* cam, const RtgsTr
 /* B frames of one shard, render side, in ONE call (ABI v7): for frame k = 0 .. n_frames-1, rtgs_project + rtgs_trace of
  * the shard seen from cams[k] (HOST array of poses) into outs[k] (HOST array of device pointers) on
  * render_streams[(first_stream + k) % n_streams], with workspaces[that stream] (and attenuation_bufs / ray_starts
- * [that stream] for depth > RTGS_MAX_DEPTH; both arrays may be NULL otherwise).  Every stream used first waits for
+ * [that stream] for depth > RTGS_MAX_DEPTH; both arrays may be NULL otherwise).  When workspace_bytes (the size of
+ * EACH stream's workspace) has room for G >= 2 frames (rtgs_workspace_bytes_frames), depth <= RTGS_MAX_DEPTH and the
+ * two state arrays are NULL, runs of up to G consecutive frames whose outs[] are equally spaced share ONE launch per
+ * kernel (grid.y = frames: a small shard's frames fill the chip together instead of queueing as latency-bound
+ * launches), group g of the call on render_streams[(first_stream + g) % n_streams]; same pixels either way.
+ * Every stream used first waits for
  * reuse_event (the previous reader of the buffers behind outs[]; NULL or complete: no wait), records
  * done_events[stream] after its last frame of the call, and consumer_stream is made to wait for those events when
  * consumer_waits != 0.  The reference renders one pose per loop iteration (__main__.py:236-257); a turntable or a

@@ -112,6 +112,9 @@ namespace {
 #ifndef RTGS_WAVES_PER_SIMD_MAIN
 #define RTGS_WAVES_PER_SIMD_MAIN 7   // the whole-frame instantiation (no SH, <= 4096 slabs): 72 VGPRs
 #endif
+#ifndef RTGS_WAVES_PER_SIMD_MULTI
+#define RTGS_WAVES_PER_SIMD_MULTI 6   // the same form with frames batched into one launch (kMulti): the per-frame offsets cost registers
+#endif
 #ifndef RTGS_WAVES_PER_SIMD_SH
 #define RTGS_WAVES_PER_SIMD_SH 5   // the SH variant carries 15 basis values more per lane (c5: 1.54 ms at 5 with 2 gathers in flight, 1.60 at 4 / 4)
 #endif
@@ -254,11 +257,22 @@ struct TraceArgs {
   const int32_t* tile_bin;    // [tiles][kTileBinCap] or NULL: per-macro-tile lists, valid where the supertile's bin is
   // peel lists (rtgs_trace_lists) or NULL: instead of compositing, the launch stores every pixel's sorted DISTINCT
   // entries -- a count per pixel and [tile][RTGS_MAX_DEPTH][256 threads] Gaussian index, exponent, t1 -- for rtgs_peel
+  // frames batched into ONE launch (rtgs_shard_frames, round 5): grid.y = frames; frame b's workspace (projected
+  // records, bounds, bins, pose block) lies frame_stride BYTES behind frame b - 1's, its output out_stride FLOATS
+  // behind.  Both 0 for the one-frame launches (grid.y = 1)
+  size_t frame_stride;
+  size_t out_stride;
   int32_t* list_cnt;  // [tile][256 threads]: how many entries the pixel's list holds (no terminators: slots beyond are never written)
   int32_t* list_idx;
   float* list_w;
   float* list_t;      // (only rtgs_peel_start reads it)
 };
+
+// frame b of a batched launch: the same object in frame b's workspace region (byte offset)
+template <typename T>
+__device__ __forceinline__ T* at_frame(T* p, size_t off) {
+  return reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + off);
+}
 
 #if RTGS_COUNT
 // [0] candidates a wave evaluated (x 64 lanes = ray-Gaussian conic tests executed), [1] of those with a hit
@@ -287,7 +301,18 @@ __global__ __launch_bounds__(kThreads) void k_project(int32_t n, const float* __
                                                   float* __restrict__ slab_key,
                                                   float* __restrict__ rec, float* __restrict__ tail,
                                                   float* __restrict__ tmin, int32_t* __restrict__ bin_reset,
-                                                  const float4 region, const int32_t region_on) {
+                                                  const float4 region, const int32_t region_on,
+                                                  const size_t frame_stride) {
+  // frames batched into one launch: blockIdx.y = frame, whose workspace region (and pose block) lies
+  // blockIdx.y * frame_stride bytes behind the first one's
+  if (frame_stride) {
+    const size_t fo = (size_t)blockIdx.y * frame_stride;
+    pose = at_frame(pose, fo);
+    bbox = at_frame(bbox, fo); slab_bbox = at_frame(slab_bbox, fo); slab_key = at_frame(slab_key, fo);
+    if (super_bbox) super_bbox = at_frame(super_bbox, fo);
+    rec = at_frame(rec, fo); tail = at_frame(tail, fo); tmin = at_frame(tmin, fo);
+    if (bin_reset) bin_reset = at_frame(bin_reset, fo);
+  }
   const int g0 = blockIdx.x * blockDim.x + threadIdx.x;
   // a frame projected WITHOUT bins must not leave last frame's in the workspace: -1 = "scan for yourself"
   // (bins are only used from 32 k Gaussians up, so the first kBinSupertilesMax threads exist)
@@ -609,7 +634,14 @@ __global__ __launch_bounds__(256) void k_bin(int32_t nslabs, const float4* __res
                                               const float* __restrict__ slab_key, int32_t width, int32_t height,
                                               int32_t shift, int32_t bin_sx, int32_t stride,
                                               int32_t* __restrict__ bin_count, int32_t* __restrict__ bin_list,
-                                              int32_t* __restrict__ tile_bin, int32_t tiles_x, int32_t tiles_y) {
+                                              int32_t* __restrict__ tile_bin, int32_t tiles_x, int32_t tiles_y,
+                                              const size_t frame_stride) {
+  if (frame_stride) {      // frames batched into one launch: blockIdx.y = frame (see k_project)
+    const size_t fo = (size_t)blockIdx.y * frame_stride;
+    slab_bbox = at_frame(slab_bbox, fo); super_bbox = at_frame(super_bbox, fo); slab_key = at_frame(slab_key, fo);
+    bin_count = at_frame(bin_count, fo); bin_list = at_frame(bin_list, fo);
+    if (tile_bin) tile_bin = at_frame(tile_bin, fo);
+  }
   __shared__ int s_id[kBinCapMax];
   __shared__ float s_key[kBinCapMax];
   __shared__ float4 s_bb[RTGS_TILE_BINS ? kBinCapMax : 1];      // bounds of the listed slabs (list order)
@@ -940,10 +972,12 @@ __device__ __forceinline__ void sh_add(float4& co, const float (&Y)[RTGS_SH_COEF
 
 // kList (rtgs_trace_lists): the launch stores every ray's sorted distinct entries instead of compositing them
 // (an instantiation of its own: as a run-time branch it cost the main one five spilled VGPRs).
-template <bool kHasSh, bool kBig, int kK, int kSplit, bool kCut = false, bool kList = false>
+// kMulti (rtgs_shard_frames): frames batched into one launch, blockIdx.y = frame (an instantiation of its own: the
+// per-frame pointer offsets cost the 72-VGPR main form 20 spilled VGPRs when they were unconditional).
+template <bool kHasSh, bool kBig, int kK, int kSplit, bool kCut = false, bool kList = false, bool kMulti = false>
 __global__ __launch_bounds__(kTraceBlock * kSplit,
                              kHasSh ? (kBig && kSplit == 1 ? RTGS_WAVES_PER_SIMD_SH : RTGS_WAVES_PER_SIMD)
-                                    : (!kBig && kSplit == 1 && kK == RTGS_MAX_DEPTH ? RTGS_WAVES_PER_SIMD_MAIN
+                                    : (!kBig && kSplit == 1 && kK == RTGS_MAX_DEPTH ? (kMulti ? RTGS_WAVES_PER_SIMD_MULTI : RTGS_WAVES_PER_SIMD_MAIN)
                                                                                     : RTGS_WAVES_PER_SIMD)) void k_trace(const TraceArgs a,
                                                           const float4* __restrict__ bbox,
                                                           const float4* __restrict__ slab_bbox,
@@ -1026,6 +1060,20 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tile bounds stay in SGPRs
+  // frames batched into one launch (rtgs_shard_frames): blockIdx.y = frame; everything per-frame lies
+  // blockIdx.y * frame_stride bytes behind frame 0's (zero offset for the one-frame launches)
+  static_assert(!kMulti || (kK == RTGS_MAX_DEPTH && kSplit == 1 && !kCut && !kList), "batched frames: the plain full-list form only");
+  const int32_t* f_bin_count = a.bin_count;
+  const int32_t* f_bin_list = a.bin_list;
+  const int32_t* f_tile_bin = a.tile_bin;
+  if constexpr (kMulti) {
+    const size_t fo = (size_t)blockIdx.y * a.frame_stride;
+    bbox = at_frame(bbox, fo); slab_bbox = at_frame(slab_bbox, fo); super_bbox = at_frame(super_bbox, fo);
+    rec = at_frame(rec, fo); tail = at_frame(tail, fo); tmin = at_frame(tmin, fo);
+    if (f_bin_count) f_bin_count = at_frame(f_bin_count, fo);
+    f_bin_list = at_frame(f_bin_list, fo);
+    if (f_tile_bin) f_tile_bin = at_frame(f_tile_bin, fo);
+  }
   const int ltile = a.tile_order ? a.tile_order[blockIdx.x] : (int)blockIdx.x;
   if ((unsigned)ltile >= gridDim.x) return;   // a malformed caller-supplied order must not write out of bounds
   const int tile = a.tile_list ? a.tile_list[ltile] : a.tile_first + ltile * a.tile_step;
@@ -1115,9 +1163,9 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   int turn = 0;  // kSplit == 2: candidates of this 8x8 tile seen so far (wave-uniform)
   // this tile's supertile bin (k_bin), if the frame has bins and the bin did not overflow
   const int bin_at = ((tile / a.tiles_x) >> a.bin_shift) * a.bin_sx + ((tile % a.tiles_x) >> a.bin_shift);
-  const int bin_n = a.bin_count ? __builtin_amdgcn_readfirstlane(a.bin_count[bin_at]) : -1;
+  const int bin_n = f_bin_count ? __builtin_amdgcn_readfirstlane(f_bin_count[bin_at]) : -1;
   const bool binned = bin_n >= 0;
-  const int32_t* const bin = a.bin_list + (size_t)bin_at * a.bin_stride;
+  const int32_t* const bin = f_bin_list + (size_t)bin_at * a.bin_stride;
   // this tile's own list (k_bin wrote it iff it wrote the supertile's bin): the count and every thread's entry
   // are loaded together with bin_n above -- ONE round trip instead of bin count -> bin ids -> slab bounds
   // (when the frame's bins were NOT built -- a small shard -- these two loads read whatever the region
@@ -1125,8 +1173,8 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   // bin_n's round trip again)
   int tb_n = -1, tb_id = 0;
   if constexpr (RTGS_TILE_BINS != 0) {
-    if (a.tile_bin) {
-      const int32_t* const tb = a.tile_bin + (size_t)tile * kTileBinCap;
+    if (f_tile_bin) {
+      const int32_t* const tb = f_tile_bin + (size_t)tile * kTileBinCap;
       tb_n = __builtin_amdgcn_readfirstlane(tb[0]);
       if (tid < kTileBinCap - 1) tb_id = tb[1 + tid];
     }
@@ -1676,8 +1724,9 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
     if constexpr (RTGS_TILE_BINS != 0) {
       const int tile_f = ea->tile_list ? ea->tile_list[ltile] : ea->tile_first + ltile * ea->tile_step;
       const int bin_f = ((tile_f / ea->tiles_x) >> ea->bin_shift) * ea->bin_sx + ((tile_f % ea->tiles_x) >> ea->bin_shift);
-      if (ea->tile_bin && ea->bin_count && __builtin_amdgcn_readfirstlane(ea->bin_count[bin_f]) >= 0) {
-        const int32_t* const tb = ea->tile_bin + (size_t)tile_f * kTileBinCap;
+      const size_t fo_f = kMulti ? (size_t)blockIdx.y * ea->frame_stride : 0;
+      if (ea->tile_bin && ea->bin_count && __builtin_amdgcn_readfirstlane(at_frame(ea->bin_count, fo_f)[bin_f]) >= 0) {
+        const int32_t* const tb = at_frame(ea->tile_bin, fo_f) + (size_t)tile_f * kTileBinCap;
         const int c = __builtin_amdgcn_readfirstlane(tb[0]);
         if (c >= 0) { tbl = tb + 1; nlist = c; }
       }
@@ -1840,7 +1889,8 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
     const float cx = dcx * il, cy = dcy * il, cz = -il;
     float rcf[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) rcf[k] = ea->pose ? (float)ea->pose->rc[k] : ea->rc[k];
+    for (int k = 0; k < 9; ++k)
+      rcf[k] = ea->pose ? (float)at_frame(ea->pose, kMulti ? (size_t)blockIdx.y * ea->frame_stride : 0)->rc[k] : ea->rc[k];
     float wx = rcf[0] * cx + rcf[1] * cy + rcf[2] * cz;
     float wy = rcf[3] * cx + rcf[4] * cy + rcf[5] * cz;
     float wz = rcf[6] * cx + rcf[7] * cy + rcf[8] * cz;
@@ -2013,14 +2063,15 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   }
 #endif
   if (ea->flags & RTGS_TRACE_COMPACT) {
-    float* o = ea->sample + ((size_t)ltile * kTile * kTile + (size_t)(pi_e - mi0) * kTile + (pj_e - mj0)) * 3;
+    float* o = ea->sample + (kMulti ? (size_t)blockIdx.y * ea->out_stride : 0) +
+               ((size_t)ltile * kTile * kTile + (size_t)(pi_e - mi0) * kTile + (pj_e - mj0)) * 3;
     if (ea->flags & RTGS_TRACE_ACCUMULATE) {
       const Rgb old = *reinterpret_cast<const Rgb*>(o);
       L0 += old.r; L1 += old.g; L2 += old.b;
     }
     *reinterpret_cast<Rgb*>(o) = Rgb{L0, L1, L2};   // one 12-B store per lane
   } else if (in_img) {
-    float* o = ea->sample + pix * 3;
+    float* o = ea->sample + (kMulti ? (size_t)blockIdx.y * ea->out_stride : 0) + pix * 3;
     if (ea->flags & RTGS_TRACE_ACCUMULATE) {
       const Rgb old = *reinterpret_cast<const Rgb*>(o);
       L0 += old.r; L1 += old.g; L2 += old.b;
@@ -2165,6 +2216,24 @@ __global__ __launch_bounds__(256) void k_untile_map(RankBufs bufs, const int32_t
   o[0] = s[0]; o[1] = s[1]; o[2] = s[2];
 }
 
+// Frames batched into one launch take their camera from a pose block in device memory, one per frame region of the
+// workspace (what RtgsCamera.device_pose is for one frame): this writes up to kMaxMerge of them from the kernel
+// arguments -- no host buffer, no copy engine, stream-ordered like everything else here.
+constexpr int kMaxMerge = 8;
+struct PoseBatch { FrameCam c[kMaxMerge]; };
+static_assert(sizeof(FrameCam) % sizeof(double) == 0 && sizeof(PoseBatch) <= 1024, "pose blocks travel as kernel arguments");
+__global__ __launch_bounds__(64) void k_upload_poses(const PoseBatch batch, char* __restrict__ first_block, size_t frame_stride,
+                                                     int32_t frames) {
+  constexpr int kWords = (int)(sizeof(FrameCam) / sizeof(double));
+  // (read through the kernarg segment: a dynamically indexed by-value struct would be copied to scratch first)
+  using KDouble = const double __attribute__((address_space(4)));
+  KDouble* src = (KDouble*)__builtin_amdgcn_kernarg_segment_ptr();
+  const int t = threadIdx.x;
+  if (t < kWords)
+    for (int f = 0; f < frames; ++f)
+      reinterpret_cast<double*>(first_block + (size_t)f * frame_stride)[t] = src[f * kWords + t];
+}
+
 inline int check_launch() { return hipGetLastError() == hipSuccess ? RTGS_OK : RTGS_ELAUNCH; }
 
 }  // namespace
@@ -2223,6 +2292,20 @@ size_t rtgs_workspace_bytes_frame(int32_t n, int32_t width, int32_t height) {
   if (width <= 0 || height <= 0) return 0;
   return workspace_bytes_tiles(n, (size_t)((width + kTile - 1) / kTile) * (size_t)((height + kTile - 1) / kTile));
 }
+
+// One frame's region of a workspace that holds several (rtgs_shard_frames batches consecutive frames into one launch
+// when the stream's workspace has room): the frame's own workspace, then its pose block, rounded to 256 B.
+static size_t frame_pose_offset(int32_t n, int32_t width, int32_t height) {
+  return (rtgs_workspace_bytes_frame(n, width, height) + 15) & ~(size_t)15;
+}
+static size_t frame_region_bytes(int32_t n, int32_t width, int32_t height) {
+  return (frame_pose_offset(n, width, height) + sizeof(FrameCam) + 255) & ~(size_t)255;
+}
+size_t rtgs_workspace_bytes_frames(int32_t n, int32_t width, int32_t height, int32_t frames) {
+  if (n <= 0 || width <= 0 || height <= 0 || frames <= 0) return 0;
+  return frames == 1 ? rtgs_workspace_bytes_frame(n, width, height) : (size_t)frames * frame_region_bytes(n, width, height);
+}
+int32_t rtgs_max_frames_per_launch(void) { return kMaxMerge; }
 
 size_t rtgs_pose_bytes(void) { return sizeof(FrameCam); }
 
@@ -2332,9 +2415,15 @@ static int32_t* tile_bin_of(int32_t* bin_count, size_t nslabs, int width, int he
 
 // want_bins: build the supertile bins (rtgs_project always asks; rtgs_trace's own projection only when
 // its shard is large enough for them to pay, see trace_impl)
+// frames > 1: `frames` consecutive frames in ONE launch each of k_project / k_bin (grid.y = frames): frame b's region
+// of the workspace lies b * frame_stride bytes behind the first and ends in its pose block (pose0 = frame 0's),
+// which the kernels read instead of `cam`'s pose
 static int project_impl(const RtgsScene* scene, const RtgsCamera* cam, void* workspace,
-                        size_t workspace_bytes, rtgs_stream_t stream, bool want_bins, const float* region = nullptr) {
+                        size_t workspace_bytes, rtgs_stream_t stream, bool want_bins, const float* region = nullptr,
+                        int32_t frames = 1, size_t frame_stride = 0, const FrameCam* pose0 = nullptr) {
   if (int rc = validate(scene, cam, workspace, workspace_bytes)) return rc;
+  const FrameCam* const pose = frames > 1 ? pose0 : static_cast<const FrameCam*>(cam->device_pose);
+  const size_t fstride = frames > 1 ? frame_stride : 0;
   const size_t nn = ((size_t)scene->n + 63) & ~(size_t)63;
   float4* bbox = static_cast<float4*>(workspace);
   float* rec = reinterpret_cast<float*>(bbox + nn);
@@ -2349,30 +2438,30 @@ static int project_impl(const RtgsScene* scene, const RtgsCamera* cam, void* wor
   const float4 rgn = region ? make_float4(region[0], region[1], region[2], region[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
   static_assert(kSuper * kSlab == 1024, "k_project<1024>: one block = one group of slabs");
   if (groups)
-    hipLaunchKernelGGL(k_project<kSuper * kSlab>, dim3((scene->n + kSuper * kSlab - 1) / (kSuper * kSlab)), dim3(kSuper * kSlab), 0,
+    hipLaunchKernelGGL(k_project<kSuper * kSlab>, dim3((scene->n + kSuper * kSlab - 1) / (kSuper * kSlab), frames), dim3(kSuper * kSlab), 0,
                        static_cast<hipStream_t>(stream), scene->n, scene->position, scene->rotation,
-                       scene->scale, fc, static_cast<const FrameCam*>(cam->device_pose), bbox, slab_bbox,
+                       scene->scale, fc, pose, bbox, slab_bbox,
                        slab_bbox + nslabs, slab_key_of(slab_bbox, nn), rec, tail, tmin,
-                       (use_bins(nslabs) && !bins) ? bin_count : nullptr, rgn, region ? 1 : 0);
+                       (use_bins(nslabs) && !bins) ? bin_count : nullptr, rgn, region ? 1 : 0, fstride);
   else
-    hipLaunchKernelGGL(k_project<256>, dim3((scene->n + 255) / 256), dim3(256), 0,
+    hipLaunchKernelGGL(k_project<256>, dim3((scene->n + 255) / 256, frames), dim3(256), 0,
                        static_cast<hipStream_t>(stream), scene->n, scene->position, scene->rotation,
-                       scene->scale, fc, static_cast<const FrameCam*>(cam->device_pose), bbox, slab_bbox,
+                       scene->scale, fc, pose, bbox, slab_bbox,
                        nullptr, slab_key_of(slab_bbox, nn), rec, tail, tmin,
-                       (use_bins(nslabs) && !bins) ? bin_count : nullptr, rgn, region ? 1 : 0);
+                       (use_bins(nslabs) && !bins) ? bin_count : nullptr, rgn, region ? 1 : 0, fstride);
   if (bins) {
     const BinGeom g = bin_geom(cam->width, cam->height);
     float* keys = slab_key_of(slab_bbox, nn);
     const int tiles_x = (cam->width + kTile - 1) / kTile, tiles_y = (cam->height + kTile - 1) / kTile;
     int32_t* const tile_bin = tile_bin_of(bin_count, nslabs, cam->width, cam->height);
     if (groups)
-      hipLaunchKernelGGL(k_bin<true>, dim3(g.supertiles), dim3(256), 0, static_cast<hipStream_t>(stream), nslabs,
+      hipLaunchKernelGGL(k_bin<true>, dim3(g.supertiles, frames), dim3(256), 0, static_cast<hipStream_t>(stream), nslabs,
                          slab_bbox, slab_bbox + nslabs, keys, cam->width, cam->height, g.shift, g.sx,
-                         bin_stride_of(nslabs), bin_count, bin_count + kBinSupertilesMax, tile_bin, tiles_x, tiles_y);
+                         bin_stride_of(nslabs), bin_count, bin_count + kBinSupertilesMax, tile_bin, tiles_x, tiles_y, fstride);
     else
-      hipLaunchKernelGGL(k_bin<false>, dim3(g.supertiles), dim3(256), 0, static_cast<hipStream_t>(stream), nslabs,
+      hipLaunchKernelGGL(k_bin<false>, dim3(g.supertiles, frames), dim3(256), 0, static_cast<hipStream_t>(stream), nslabs,
                          slab_bbox, slab_bbox + nslabs, keys, cam->width, cam->height, g.shift, g.sx,
-                         bin_stride_of(nslabs), bin_count, bin_count + kBinSupertilesMax, tile_bin, tiles_x, tiles_y);
+                         bin_stride_of(nslabs), bin_count, bin_count + kBinSupertilesMax, tile_bin, tiles_x, tiles_y, fstride);
   }
   return check_launch();
 }
@@ -2414,8 +2503,12 @@ static PeelLists peel_lists_of(void* lists, int32_t width, int32_t height) {
 static int trace_impl(const RtgsScene* scene, const RtgsCamera* cam, const RtgsTraceParams* params,
                       float* sample_buf, float* attenuation_buf, float* ray_start,
                       int32_t ray_start_stride, void* workspace, size_t workspace_bytes,
-                      int32_t projected, int32_t tile_limit, rtgs_stream_t stream, void* lists = nullptr) {
+                      int32_t projected, int32_t tile_limit, rtgs_stream_t stream, void* lists = nullptr,
+                      int32_t frames = 1, size_t frame_stride = 0, size_t out_stride = 0, const FrameCam* pose0 = nullptr) {
   if (!params || (!sample_buf && !lists)) return RTGS_EINVAL;
+  if (frames > 1 && (lists || attenuation_buf || ray_start || params->depth > RTGS_MAX_DEPTH || params->depth < 2 ||
+                     params->t_cutoff > 0.f))
+    return RTGS_EINVAL;     // (rtgs_shard_frames only batches what the plain full-list form renders)
   if (int rc = validate(scene, cam, workspace, workspace_bytes)) return rc;
   if (params->depth < 1) return RTGS_EDEPTH;
   if (params->depth > RTGS_MAX_DEPTH && !lists) {
@@ -2453,8 +2546,13 @@ static int trace_impl(const RtgsScene* scene, const RtgsCamera* cam, const RtgsT
   if (local > tile_limit) local = tile_limit;
   if (local <= 0) return RTGS_OK;  // a shard with no tiles
   if (!projected) {
-    if (int rc = project_impl(scene, cam, workspace, workspace_bytes, stream, shard_wants_bins(cam, local),
-                              (params->flags & RTGS_TRACE_REGION) ? params->region : nullptr)) return rc;
+    // (frames batched into one launch: the chip is throughput-bound, and the launch as a whole decides whether k_bin pays)
+    bool want_bins = shard_wants_bins(cam, (int32_t)std::min<int64_t>((int64_t)local * frames, INT32_MAX));
+    if (params->flags & RTGS_TRACE_BINS_ON) want_bins = true;
+    if (params->flags & RTGS_TRACE_BINS_OFF) want_bins = false;
+    if (int rc = project_impl(scene, cam, workspace, workspace_bytes, stream, want_bins,
+                              (params->flags & RTGS_TRACE_REGION) ? params->region : nullptr, frames, frame_stride, pose0))
+      return rc;
   }
 
   const size_t nn = ((size_t)scene->n + 63) & ~(size_t)63;
@@ -2474,7 +2572,9 @@ static int trace_impl(const RtgsScene* scene, const RtgsCamera* cam, const RtgsT
   a.inv_fx = (float)fc.inv_fx;
   a.inv_fy = (float)fc.inv_fy;
   for (int k = 0; k < 9; ++k) a.rc[k] = (float)fc.rc[k];
-  a.pose = static_cast<const FrameCam*>(cam->device_pose);
+  a.pose = frames > 1 ? pose0 : static_cast<const FrameCam*>(cam->device_pose);
+  a.frame_stride = frames > 1 ? frame_stride : 0;
+  a.out_stride = frames > 1 ? out_stride : 0;
   a.bin_count = nullptr; a.bin_list = nullptr; a.bin_stride = 0; a.bin_shift = 0; a.bin_sx = 1; a.tile_bin = nullptr;
   if (use_bins((int)(nn / kSlab))) {
     const BinGeom g = bin_geom(cam->width, cam->height);
@@ -2531,6 +2631,8 @@ static int trace_impl(const RtgsScene* scene, const RtgsCamera* cam, const RtgsT
                                   bbox, slab_bbox, super_bbox, rec, tail, tmin, colop, sh);                              \
     else if (cut) hipLaunchKernelGGL((k_trace<HAS_SH, BIG, RTGS_MAX_DEPTH, 1, true>), dim3(local), dim3(kTraceBlock), 0, s, a, \
                                 bbox, slab_bbox, super_bbox, rec, tail, tmin, colop, sh);                                \
+    else if (frames > 1) hipLaunchKernelGGL((k_trace<HAS_SH, BIG, RTGS_MAX_DEPTH, 1, false, false, true>), dim3(local, frames), dim3(kTraceBlock), 0, s, a, \
+                                            bbox, slab_bbox, super_bbox, rec, tail, tmin, colop, sh);                    \
     else if (k1) RTGS_LAUNCH(HAS_SH, BIG, 1, 1);                                    \
     else if (split) RTGS_LAUNCH(HAS_SH, BIG, RTGS_MAX_DEPTH, 2);                    \
     else RTGS_LAUNCH(HAS_SH, BIG, RTGS_MAX_DEPTH, 1);                               \
@@ -2712,14 +2814,60 @@ int rtgs_shard_frames(const RtgsScene* scene, const RtgsCamera* cams, int32_t n_
   }
   // an EMPTY share (explicit tile list of no tiles) renders nothing: its frames only take part in the event chain
   const bool empty_share = params && (params->flags & RTGS_TRACE_TILE_LIST) && params->tile_count == 0;
-  for (int32_t k = 0; k < n_frames && !empty_share; ++k) {
-    const int32_t si = (first_stream + k) % n_streams;
-    if (!outs[k]) return RTGS_EINVAL;
-    if (int rc = trace_impl(scene, &cams[k], params, outs[k], attenuation_bufs ? attenuation_bufs[si] : nullptr,
-                            ray_starts ? ray_starts[si] : nullptr, 1, workspaces[si], workspace_bytes, 0, INT32_MAX,
-                            render_streams[si]))
-      return rc;
+  // Frames that can share a launch: consecutive frames of one stream whose outputs are equally spaced, when the
+  // stream's workspace has room for their regions (rtgs_workspace_bytes_frames) -- ONE k_project, k_bin and k_trace
+  // with grid.y = frames instead of one latency-bound chain of small launches per frame: a 1/8 shard of a 1080p frame
+  // is one resident round of workgroups, eight of them in one grid fill the chip like a whole frame does.
+  int32_t merge = 1;
+  size_t region = 0, pose_off = 0;
+  if (!empty_share && n_frames > 1 && scene && params && !attenuation_bufs && !ray_starts && params->depth <= RTGS_MAX_DEPTH &&
+      params->depth >= 2 && !(params->t_cutoff > 0.f) && cams[0].width > 0 && cams[0].height > 0) {
+    region = frame_region_bytes(scene->n, cams[0].width, cams[0].height);
+    pose_off = frame_pose_offset(scene->n, cams[0].width, cams[0].height);
+    const size_t room = region ? workspace_bytes / region : 0;
+    merge = (int32_t)(room < (size_t)kMaxMerge ? room : (size_t)kMaxMerge);
+    if (merge < 1) merge = 1;
   }
+  int32_t group = 0;
+  for (int32_t k = 0; k < n_frames && !empty_share;) {
+    // group `group` of this call runs on stream (first_stream + group) % n_streams
+    const int32_t si = (first_stream + (merge > 1 ? group : k)) % n_streams;
+    if (!outs[k]) return RTGS_EINVAL;
+    int32_t g = 1;
+    ptrdiff_t step = 0;
+    if (merge > 1) {
+      while (k + g < n_frames && g < merge) {
+        if (!outs[k + g] || cams[k + g].device_pose || cams[k].device_pose || cams[k + g].width != cams[k].width ||
+            cams[k + g].height != cams[k].height || cams[k + g].fx != cams[k].fx || cams[k + g].fy != cams[k].fy) break;
+        const ptrdiff_t d = outs[k + g] - outs[k + g - 1];
+        if (g == 1) step = d;
+        if (d != step || d <= 0) break;
+        ++g;
+      }
+    }
+    if (g > 1) {
+      PoseBatch batch;
+      for (int32_t b = 0; b < g; ++b) batch.c[b] = make_frame_cam(cams[k + b]);
+      for (int32_t b = g; b < kMaxMerge; ++b) batch.c[b] = batch.c[0];
+      char* const ws = static_cast<char*>(workspaces[si]);
+      if (!ws) return RTGS_EINVAL;
+      hipLaunchKernelGGL(k_upload_poses, dim3(1), dim3(64), 0, static_cast<hipStream_t>(render_streams[si]), batch,
+                         ws + pose_off, region, g);
+      if (int rc = trace_impl(scene, &cams[k], params, outs[k], nullptr, nullptr, 1, ws, region, 0, INT32_MAX,
+                              render_streams[si], nullptr, g, region, (size_t)step,
+                              reinterpret_cast<const FrameCam*>(ws + pose_off)))
+        return rc;
+    } else {
+      if (int rc = trace_impl(scene, &cams[k], params, outs[k], attenuation_bufs ? attenuation_bufs[si] : nullptr,
+                              ray_starts ? ray_starts[si] : nullptr, 1, workspaces[si], workspace_bytes, 0, INT32_MAX,
+                              render_streams[si]))
+        return rc;
+    }
+    k += g;
+    ++group;
+  }
+  // (which streams carried work: with merged groups the first min(groups, n_streams) from first_stream on, without
+  // merging the first min(n_frames, n_streams): `used` below covers both -- recording an event on an idle stream is harmless)
   for (int32_t u = 0; u < used; ++u) {
     const int32_t si = (first_stream + u) % n_streams;
     hipEvent_t ev = static_cast<hipEvent_t>(done_events[si]);

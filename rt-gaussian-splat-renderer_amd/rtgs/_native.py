@@ -26,6 +26,8 @@ TRACE_SPLIT_ON = 8     # scheduling only: force / forbid two waves per 8x8 tile
 TRACE_SPLIT_OFF = 16
 TRACE_TILE_LIST = 32   # the shard is RtgsTraceParams.tile_list / tile_count (an empty list renders nothing)
 TRACE_REGION = 64      # the shard lies inside RtgsTraceParams.region: its projection skips what cannot reach it
+TRACE_BINS_ON = 128    # scheduling only: force / forbid the per-frame slab bins for the call's own projection
+TRACE_BINS_OFF = 256
 PEEL_FRESH = 1
 
 LIB_PATH = os.environ.get("RTGS_HIP_LIB") or os.path.join(
@@ -68,6 +70,8 @@ PROTOTYPES = {
     "rtgs_generate_rays": (c_int32, [POINTER(RtgsCamera), c_void_p, c_void_p]),
     "rtgs_workspace_bytes": (c_size_t, [c_int32]),
     "rtgs_workspace_bytes_frame": (c_size_t, [c_int32, c_int32, c_int32]),
+    "rtgs_workspace_bytes_frames": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
+    "rtgs_max_frames_per_launch": (c_int32, []),
     "rtgs_pose_bytes": (c_size_t, []),
     "rtgs_pose_pack": (c_int32, [POINTER(RtgsCamera), c_void_p]),
     "rtgs_tile_size": (c_int32, []),

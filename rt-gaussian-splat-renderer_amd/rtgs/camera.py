@@ -28,6 +28,7 @@ class Camera:
         # pose the ray field was last generated for: what sample_step traces
         self.field_position = vec3(position)
         self.field_rotation = vec4(rotation)
+        self.ray_field_generation = 0    # counts generate_ray_field() calls (not the tracer's deferred regenerations)
 
     def native(self, position=None, rotation=None, device_pose=None) -> nat.RtgsCamera:
         return nat.make_camera(self.position if position is None else position,
@@ -54,6 +55,7 @@ class Camera:
         tracer, not in this field) settles that part first (``RayField.supersede``) -- regenerating the
         rays supersedes the ``.start`` column, not the attenuation the eager calls would have left."""
         self.cam_ray_field.supersede()
+        self.ray_field_generation += 1      # (RayTracer: a listed sample in progress no longer matches the field's .start)
         self._generate(position, rotation)
         self.cam_ray_field.defer(None, False)      # up to date; supersedes any deferred update
         self.field_position = vec3(position)

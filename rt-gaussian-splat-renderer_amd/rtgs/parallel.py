@@ -14,16 +14,17 @@ Where a frame lands (``landing``):
             xGMI) of W*H*12/world bytes per rank.  What a single display loop wants
             (/root/reference's consumer is one, __main__.py:253-257) -- and a bound: the root receives
             (world-1)/world of every frame, one shard per link, and untiles every frame.
-  "rotate"  (round 5) frame f on rank f mod world.  A batch of B = k * world consecutive frames
-            travels in ONE ``all_to_all_single``: rank r receives, from everybody, the shards of the
-            batch's frames r, r + world, ... -- world gathers with world different roots in one
-            collective, every xGMI link carrying 1/world of what the single root's links carry,
-            every rank untiling one frame in world.  For consumers that can take frames from any
-            rank (an encoder per GPU, a throughput benchmark).
+  "rotate"  (round 5) the roots rotate: frame f on rank f mod world when a batch is world frames; in
+            general a batch of B = k * world consecutive frames travels in ONE ``all_to_all_single`` and
+            rank d receives, from everybody, the shards of the batch's frames [d k, (d + 1) k) -- world
+            gathers with world different roots in one collective, every xGMI link carrying 1/world of
+            what the single root's links carry, every rank untiling one frame in world.  For consumers
+            that can take frames from any rank (an encoder per GPU, a throughput benchmark).
 
 ``render_frames(poses)`` queues any number of frames from an array of poses: per batch one library
-call on the render side (``rtgs_shard_frames``: B x [project -> trace] over the F render streams),
-one collective, one landing call (``rtgs_frames_land``).
+call on the render side (``rtgs_shard_frames``: the batch's frames in runs of up to 8 per LAUNCH --
+one k_project / k_bin / k_trace with grid.y = frames, so that small shards fill the chip together --
+dealt over the F render streams), one collective, one landing call (``rtgs_frames_land``).
 
 Round 4: the deal need not be equal.  ``Partition`` names every rank's tiles explicitly (``RtgsTraceParams.tile_list``),
 ``Partition.weighted`` gives every rank its own share, the exchange is then point to point (each shard's own bytes) and
@@ -459,9 +460,10 @@ class TileParallelRenderer:
     """Renders whole frames on `world` ranks; where they land is ``landing``:
 
     ``"root"`` (default): every frame in ``framebuffer`` on rank `dst`, by one gather per batch.
-    ``"rotate"``: frame f on rank f mod world, by ONE ``all_to_all_single`` per batch of B = k * world frames --
-    every rank is the root of k of the batch's frames (``landed_frames()`` names them), every xGMI link carries
-    1/world of the single root's inbound traffic and every rank untiles one frame in world.
+    ``"rotate"``: the roots rotate -- of every batch of B = k * world frames the k frames [d k, (d + 1) k) land on
+    rank d (frame f on rank f mod world when B = world), by ONE ``all_to_all_single`` per batch: every rank is the
+    root of k of the batch's frames (``landed_frames()`` names them, ``destination(f)`` says where frame f goes),
+    every xGMI link carries 1/world of the single root's inbound traffic and every rank untiles one frame in world.
 
     ``frames_in_flight`` (default 2, ``RTGS_FRAMES_IN_FLIGHT``): a 1/8 shard of a 1080p frame is ONE
     resident round of workgroups, so its trace takes as long as its heaviest tile's dependency chain
@@ -616,24 +618,30 @@ class TileParallelRenderer:
         numbers count ``render_frame`` calls from 0.  Valid in the caller's stream order until the next batch lands."""
         return [(f, self._fbs[i]) for f, i in self._landed_frames]
 
-    def _batch_position(self, j: int) -> int:
-        """Where frame j of a batch sits in the batch's send buffer: rotating roots group the frames by destination
-        (frame j lands on rank j mod world: block j mod world, position j div world)."""
+    def destination(self, frame: int) -> int:
+        """The rank frame number `frame` lands on.  Rotating roots: the k = B / world frames [d k, (d + 1) k) of every
+        batch land on rank d -- frame f on rank f mod world when a batch is world frames -- so that a rank's block of
+        the batch's send buffer is k CONSECUTIVE frames (all_to_all_single wants one contiguous block per destination,
+        and consecutive frames of equal spacing can share a launch)."""
         if self.landing == "rotate":
-            return (j % self.world) * self.per_dest + j // self.world
+            return (frame % self.gather_batch) // self.per_dest
+        return self.dst
+
+    def _batch_position(self, j: int) -> int:
+        """Where frame j of a batch sits in the batch's send buffer (in batch order, for both landings)."""
         return j
 
     def _lands_here(self, n_valid: int) -> int:
         """How many of a batch's first n_valid frames land on this rank."""
         if self.landing == "rotate":
-            return max(0, (n_valid - self.rank + self.world - 1) // self.world)
+            return max(0, min(self.per_dest, n_valid - self.rank * self.per_dest))
         return n_valid if self._fbs else 0
 
     def _note_landed(self, batch: int, n_land: int) -> None:
         if n_land:
             B = self.gather_batch
-            step, first = (self.world, self.rank) if self.landing == "rotate" else (1, 0)
-            self._landed_frames = [(batch * B + first + i * step, i) for i in range(n_land)]
+            first = self.rank * self.per_dest if self.landing == "rotate" else 0
+            self._landed_frames = [(batch * B + first + i, i) for i in range(n_land)]
             self._landed = n_land - 1
 
     def _make_stream_state(self, F: int, B: int):
@@ -650,16 +658,32 @@ class TileParallelRenderer:
             nat.check(lib.rtgs_event_create(ctypes.byref(h)), "rtgs_event_create")
             return h.value
 
+        # RTGS_SHARD_BINS: 1 / 0 force / forbid the per-frame slab bins for this rank's shards, auto (default) leaves
+        # the choice to the library (bins from a sixth of the frame's tiles)
+        flags = nat.TRACE_COMPACT | {"1": nat.TRACE_BINS_ON, "0": nat.TRACE_BINS_OFF}.get(os.environ.get("RTGS_SHARD_BINS", "auto"), 0)
         if self._shard is not None:
             order = self._shard["order"]
-            params = b.shard_params(self._shard, nat.TRACE_COMPACT)
+            params = b.shard_params(self._shard, flags)
         else:
             order = b.tile_order(self.rank, self.world) if (b.use_tile_order and self.local_tiles) else None
-            params = nat.RtgsTraceParams(b.depth, b.t_cutoff, self.rank, self.world, nat.TRACE_COMPACT, nat.ptr(order))
-        ws = [b.workspace] + [torch.empty_like(b.workspace) for _ in range(F - 1)]
+            params = nat.RtgsTraceParams(b.depth, b.t_cutoff, self.rank, self.world, flags, nat.ptr(order))
         state = [(None, None)] * F
         if b.depth > nat.MAX_DEPTH:      # chained launches need per-pixel state, one pair per frame in flight
             state = [(b.alloc(b.width, b.height), b.alloc(b.width, b.height)) for _ in range(F)]
+        # Frames per LAUNCH (RTGS_MERGE_FRAMES, default: as many of a batch as the library takes, 8): every render
+        # stream's workspace holds that many frames' regions, and rtgs_shard_frames renders runs of consecutive frames
+        # with one k_project / k_bin / k_trace each (grid.y = frames) -- a 1/8 shard of a 1080p frame is one resident
+        # round of workgroups whose trace takes as long as its heaviest tile; eight of them in one grid fill the chip
+        merge = int(os.environ.get("RTGS_MERGE_FRAMES", "0")) or lib.rtgs_max_frames_per_launch()
+        merge = max(1, min(merge, B, lib.rtgs_max_frames_per_launch()))
+        if b.depth > nat.MAX_DEPTH or b.depth < 2 or b.t_cutoff > 0:
+            merge = 1                    # (chained launches, the single-peel and the cut-off forms render frame by frame)
+        self.frames_per_launch = merge
+        if merge > 1:
+            need = lib.rtgs_workspace_bytes_frames(b.scene.num_gaussians, b.width, b.height, merge)
+            ws = [torch.empty(need, dtype=torch.uint8, device=b.device) for _ in range(F)]
+        else:
+            ws = [b.workspace] + [torch.empty_like(b.workspace) for _ in range(F - 1)]
         images = (ctypes.c_void_p * len(self._fbs))(*[fb.data_ptr() for fb in self._fbs]) if self._fbs else None
         self._counts_c = (ctypes.c_int32 * self.world)(*self.partition.counts)
         render = [torch.cuda.Stream(device=b.device) for _ in range(F)]
@@ -670,7 +694,7 @@ class TileParallelRenderer:
                     ws_c=(ctypes.c_void_p * F)(*[w.data_ptr() for w in ws]),
                     att_c=(ctypes.c_void_p * F)(*[nat.ptr(a) for a, _ in state]) if state[0][0] is not None else None,
                     start_c=(ctypes.c_void_p * F)(*[nat.ptr(st) for _, st in state]) if state[0][0] is not None else None,
-                    sent=[event() for _ in range(self._slots)], seen=[None] * F,
+                    sent=[event() for _ in range(self._slots)], seen=[None] * F, turn=0,
                     params=params, order=order, images=images, g=0, lib=lib)
 
     def close(self) -> None:
@@ -745,8 +769,10 @@ class TileParallelRenderer:
                                            for i in range(m)])
             nat.check(cm["lib"].rtgs_shard_frames(
                 b.scene_native(), cams.ctypes.data + done * cams.itemsize, m, cm["params"], outs, cm["att_c"], cm["start_c"],
-                cm["ws_c"], cm["ws"][0].numel(), cm["streams_c"], F, f % F, cm["sent"][slot], cm["done_c"][slot], cur, 1),
-                "rtgs_shard_frames")
+                cm["ws_c"], cm["ws"][0].numel(), cm["streams_c"], F, cm["turn"] % F, cm["sent"][slot], cm["done_c"][slot],
+                cur, 1), "rtgs_shard_frames")
+            # (the library deals the call's launches -- runs of up to frames_per_launch frames -- over the streams in turn)
+            cm["turn"] += -(-m // self.frames_per_launch)
             self._frame += m
             done += m
             if j0 + m == B:

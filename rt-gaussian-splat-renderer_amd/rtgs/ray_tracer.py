@@ -50,6 +50,7 @@ class RayTracer:
         self._list_peels = None      # peels of the CURRENT sample composited from the lists; None = not in step with them
         self._state_peels = 0        # peels the ray field's deferred .start update has to account for (rtgs_peel_start)
         self._sample_pose = None     # (position, rotation) the listed sample in progress was started from
+        self._list_gen = -1          # camera.ray_field_generation when the last listed peel was composited
 
     @property
     def attenuation_buf(self) -> torch.Tensor:
@@ -210,7 +211,10 @@ class RayTracer:
             else:
                 self.camera.defer_ray_field(pos, rot, lambda: self._regenerate_keeping_start(pos, rot), False)
         k = self.num_steps
+        # (a generate_ray_field() since the last listed peel put .start back to 0: the reference's next sample_step
+        # peels the NEAREST entry again -- found by tests/test_gpu_state_machine.py, round 5)
         listed = (self._list_peels == k and k < nat.MAX_DEPTH and (first or not f.edited) and
+                  (first or self._list_gen == self.camera.ray_field_generation) and
                   self._lists_for is not None and self._lists_for[1] == self.scene.geometry_key())
         if listed:
             pos, rot = self._sample_pose
@@ -221,6 +225,7 @@ class RayTracer:
             self._replay_owed = False
             # .start (and the rays) are owed again: what a reader sees is the state after k + 1 peels
             self.camera.defer_ray_field(pos, rot, lambda: self._start_from_lists(pos, rot), True)
+            self._list_gen = self.camera.ray_field_generation
         else:
             self.sample_step(_fresh=first and self._list_peels is None)
         self.num_steps += 1

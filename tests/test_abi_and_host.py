@@ -81,9 +81,10 @@ def test_argument_validation_needs_no_gpu():
     assert lib.rtgs_frames_land(None, 1, 1, 2, 3, 4, 4, None, None, None) == -1       # n_land > batch
     cam = nat.make_camera((0, 0, 0), (0, 0, 0, 1), 64, 64, 64.0, 64.0)
     assert lib.rtgs_trace(None, cam, None, None, None, None, 1, None, 0, 0, None) == -1
-    # peel lists (ABI v6): 16 slots x (index, exponent, t1) per thread of every macro-tile
+    # peel lists (ABI v7): a count + 16 slots x (index, exponent, t1) per thread of every macro-tile
     t = lib.rtgs_tile_size()
-    assert lib.rtgs_peel_list_bytes(1920, 1080) == lib.rtgs_num_tiles(1920, 1080) * 16 * t * t * 12
+    assert lib.rtgs_peel_list_bytes(1920, 1080) == lib.rtgs_num_tiles(1920, 1080) * t * t * (4 + 16 * 12)
+    assert lib.rtgs_shard_frames(None, None, 1, None, None, None, None, None, 0, None, 1, 0, None, None, None, 0) == -1
     assert lib.rtgs_peel_list_bytes(0, 8) == 0
     assert lib.rtgs_trace_lists(None, cam, None, None, 0, None, 0, 0, None) == -1
     assert lib.rtgs_peel(None, cam, None, 0, 0, 0, None, None, None) == -1

@@ -1214,7 +1214,7 @@ class _RotatingComm:
             else:
                 per = self.counts[s] * self.elems
                 for i in range(k):
-                    f = q * B + i * N + me
+                    f = q * B + me * k + i           # the frames [me k, (me + 1) k) of batch q land here
                     if f < len(self.shards) and per:
                         blk[i * per:(i + 1) * per].copy_(self.shards[f][s].reshape(-1)[:per], non_blocking=True)
             off += size
@@ -1224,7 +1224,8 @@ class _RotatingComm:
     (0, 2, 4, None, (1,) * 11), (3, 2, 8, None, (5, 6)), (1, 3, 4, None, (11,)), (2, 1, 4, None, (3, 3, 3, 2)),
     (0, 2, 4, (5, 1, 1, 1), (4, 7)), (2, 3, 8, (2, 3, 0, 1), (11,)), (1, 2, 4, "wedges", (2, 9))])
 def test_rotating_roots_land_their_frames_bit_exact_without_host_syncs(rank, in_flight, batch, shares, calls):
-    # round 5: landing="rotate" -- frame f lands on rank f mod 4 -- through the real stream path:
+    # round 5: landing="rotate" -- the roots rotate: frame f on rank f mod 4 with 4 frames per batch, two
+    # consecutive frames per rank with 8 -- through the real stream path:
     # rtgs_shard_frames queues several frames per call from an array of poses over F render streams, ONE
     # all_to_all per batch (stand-in: ordered on the caller's stream only), rtgs_frames_land(_map) lands this rank's k
     # frames of the batch.  Eleven poses (a partial last batch), two in-place scene edits between calls, no host
@@ -1291,7 +1292,8 @@ def test_rotating_roots_land_their_frames_bit_exact_without_host_syncs(rank, in_
     for f, img in r0.landed_frames():
         got.setdefault(f, img.clone())
     torch.cuda.synchronize()
-    mine = [f for f in range(len(poses)) if f % world == rank]
+    mine = [f for f in range(len(poses)) if r0.destination(f) == rank]
+    assert all((f % batch) // (batch // world) == rank for f in mine)
     seen_all = max(calls) <= batch           # a call that ends two batches lets the first one's frames be overwritten
     for f in mine:
         if f in got:

@@ -111,8 +111,9 @@ def _worker(rank, world, port, frames, q, in_flight=2, shares=None):
 
 
 def _rotate_worker(rank, world, port, frames, q, batch, shares, poses_per_call):
-    """landing="rotate": frame f lands on rank f mod world, one all_to_all_single per batch of B frames; EVERY landed
-    frame is checked on the rank that holds it, after every batch and after the partial last one."""
+    """landing="rotate": of every batch of B = k world frames the frames [d k, (d + 1) k) land on rank d, one
+    all_to_all_single per batch; EVERY landed frame is checked on the rank that holds it, after every batch and
+    after the partial last one."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -126,7 +127,7 @@ def _rotate_worker(rank, world, port, frames, q, batch, shares, poses_per_call):
 
         def check():
             for f, img in r.landed_frames():
-                assert f % world == rank
+                assert r.destination(f) == rank == (f % B) // (B // world)
                 if f not in seen:            # (a batch that lands nothing here leaves the previous one's frames named)
                     seen[f] = float((img - image * float(f + 1)).abs().max())
 
@@ -153,7 +154,7 @@ def _rotate_worker(rank, world, port, frames, q, batch, shares, poses_per_call):
     (2, 5, 2, (3, 1), 1), (3, 8, 3, (5, 0, 1), 2), (3, 4, 6, "wedges", 4), (4, 6, 8, (1, 2, 0, 4), 6)])
 def test_rotating_roots_land_every_frame_on_its_rank(world, frames, batch, shares, per_call):
     # world-2/3/4, equal / unequal / empty shares, several frames per call, a partial last batch:
-    # every frame of the LAST complete-or-partial batch and of every batch before it must be bit-exact on rank f mod world
+    # every frame of the LAST complete-or-partial batch and of every batch before it must be bit-exact on its rank
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     mp.spawn(_rotate_worker, args=(world, _free_port(), frames, q, batch, shares, per_call), nprocs=world, join=True)
@@ -162,7 +163,7 @@ def test_rotating_roots_land_every_frame_on_its_rank(world, frames, batch, share
     landed = {}
     for rank, seen in got.items():
         for f, err in seen.items():
-            assert f % world == rank and err == 0.0, (rank, f, err)
+            assert (f % B) // (B // world) == rank and err == 0.0, (rank, f, err)
             landed[f] = rank
     # batches are only looked at when a call crosses their end (the ring of k framebuffers is overwritten by the next
     # batch): the last batch -- complete or partial -- is always seen in full

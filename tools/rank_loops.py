@@ -68,7 +68,7 @@ for name in (sys.argv[1:] or ["c3", "c5"]):
                         continue
                     for F in Fs:
                         per, host = [], []
-                        for rank in range(world):
+                        for rank in ([int(v) for v in os.environ["RANKS"].split()] if os.environ.get("RANKS") else range(world)):
                             r = TileParallelRenderer(scene, camera, depth=cfg.depth, rank=rank, world=world, gather_fn=_no_gather,
                                                      p2p_fn=lambda mine, landing: [], a2a_fn=_no_all_to_all, partition=part,
                                                      frames_in_flight=F, gather_batch=B, landing=landing)
