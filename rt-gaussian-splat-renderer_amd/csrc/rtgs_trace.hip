@@ -113,7 +113,7 @@ namespace {
 #define RTGS_WAVES_PER_SIMD_MAIN 7   // the whole-frame instantiation (no SH, <= 4096 slabs): 72 VGPRs
 #endif
 #ifndef RTGS_WAVES_PER_SIMD_MULTI
-#define RTGS_WAVES_PER_SIMD_MULTI 6   // the same form with frames batched into one launch (kMulti): the per-frame offsets cost registers
+#define RTGS_WAVES_PER_SIMD_MULTI 7   // the same form with frames batched into one launch (kMulti): 72 VGPRs, no scratch, 32 SGPR spills (main: 23)
 #endif
 #ifndef RTGS_WAVES_PER_SIMD_SH
 #define RTGS_WAVES_PER_SIMD_SH 5   // the SH variant carries 15 basis values more per lane (c5: 1.54 ms at 5 with 2 gathers in flight, 1.60 at 4 / 4)
@@ -269,9 +269,13 @@ struct TraceArgs {
 };
 
 // frame b of a batched launch: the same object in frame b's workspace region (byte offset)
+// (pointer arithmetic, NOT an integer round trip: through uintptr_t the result loses its provenance -- no longer
+// "based on" the const __restrict__ kernel argument -- and the wave-uniform record loads of the candidate loop come
+// out as vector loads instead of s_load_dwordx16: the batched form ran 1.5 x slower per tile that way)
 template <typename T>
 __device__ __forceinline__ T* at_frame(T* p, size_t off) {
-  return reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + off);
+  using Byte = typename std::conditional<std::is_const<T>::value, const char, char>::type;
+  return reinterpret_cast<T*>(reinterpret_cast<Byte*>(p) + off);
 }
 
 #if RTGS_COUNT

@@ -61,6 +61,8 @@ for name in (sys.argv[1:] or ["c3", "c5"]):
             parts.append(("equal", Partition.round_robin(total, world)))
         if "wedges" in deals:
             parts.append(("wedges", Partition.wedges(cfg.width, cfg.height, nat.tile_size(), world)))
+        if "all0" in deals:       # rank 0 renders EVERY tile through an explicit list (a whole frame through the shard path)
+            parts.append(("all0", Partition.weighted(total, [1.0] + [0.0] * (world - 1))))
         for dname, part in parts:
             for landing in ("root", "rotate"):
                 for B in Bs:
