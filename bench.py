@@ -530,6 +530,10 @@ def rank_main(args) -> int:
             modes += [(p_, "root", gb) for p_ in parts if p_ != "auto" and gb > 1]
         if "rotate" in landings:      # (rotating roots: every rank is a destination as often as any other -- no "auto")
             modes += [(p_, "rotate", gb) for p_ in parts if p_ != "auto"]
+            if args.partition == "both" and "wedges" not in parts:
+                # one compact image sector per rank, its projection culled to it: the fastest deal of the every-rank
+                # emulation once frames are batched (profiles/r05_shards.txt)
+                modes.append(("wedges", "rotate", gb))
     def emit_line(best, reported, abandoned=None, frame_ms_median=None):
         """Rank 0: the ONE JSON line, from a finished run of a tile deal (`best` = a run_mode result)."""
         renderer, batches, elapsed = best["renderer"], best["batches"], best["elapsed"]

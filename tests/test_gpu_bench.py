@@ -42,7 +42,7 @@ def test_bare_bench_with_two_ranks_starts_them_itself_and_verifies(extra, env):
     # per library call and collective, landing on rank 0 and on ROTATING roots (one all_to_all per batch)
     gb = extra[1] if extra else "8"
     parts = line["secondary"]["partitions"]
-    assert set(parts) == {"equal/root/B1", "auto/root/B1", f"equal/root/B{gb}", f"equal/rotate/B{gb}"}
+    assert set(parts) == {"equal/root/B1", "auto/root/B1", f"equal/root/B{gb}", f"equal/rotate/B{gb}", f"wedges/rotate/B{gb}"}
     assert all(p is not None and p["verified"] is True for p in parts.values())
     assert parts["equal/root/B1"]["deal"] == "round-robin" and line["secondary"]["partition_reported"] in parts
     assert parts[f"equal/rotate/B{gb}"]["landing"] == "rotate" and parts[f"equal/rotate/B{gb}"]["frames_per_collective"] == int(gb)
