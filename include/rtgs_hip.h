@@ -86,10 +86,8 @@ typedef struct RtgsCamera {
                                      shard's pixels are overwritten                          */
 #define RTGS_TRACE_COMPACT 4u     /* sample_buf is the shard-compact [local_tile][T][T][3], T = rtgs_tile_size(),
                                      buffer that rtgs_untile scatters, not the (W,H,3) image  */
-/* scheduling only, same pixels: force / forbid the two-waves-per-8x8-tile form of the kernel
- * that launches of few tiles (small shards) get by default */
-#define RTGS_TRACE_SPLIT_ON 8u
-#define RTGS_TRACE_SPLIT_OFF 16u
+/* (8u and 16u were RTGS_TRACE_SPLIT_ON / _OFF up to ABI v6 -- the two-waves-per-8x8-tile form of the kernel, retired
+ * in round 5: the bits are ignored) */
 #define RTGS_TRACE_TILE_LIST 32u  /* the shard is tile_list[0 .. tile_count) (ABI v6), not (tile_first, tile_step);
                                      tile_count = 0 (an empty share) renders nothing */
 #define RTGS_TRACE_REGION 64u     /* the shard's tiles all lie inside RtgsTraceParams.region: the projection this call

@@ -24,7 +24,7 @@
 //     wave also reduces the slab's union screen bound and a depth key.  With the scene stored in
 //     Morton order (rtgs.Scene does that at load) a slab is spatially compact: its bound is tight.
 //   * k_trace: one workgroup per RTGS_TILE x RTGS_TILE macro-tile, one wave64 per 8x8 pixel
-//     tile (two for small launches, kSplit), one lane per ray.  The workgroup scans the slab
+//     tile, one lane per ray.  The workgroup scans the slab
 //     bounds (16 B per 64 Gaussians; in two levels for big scenes), keeps the slabs that touch
 //     the macro-tile (deterministic ballot/prefix compaction into LDS), orders them nearest
 //     first, expands them -- one wave per slab, one lane per Gaussian, 16 B bounds, SoA in HBM
@@ -67,7 +67,7 @@ namespace {
 //    SQ_INSTS_VALU 83.5 M -> 78.0 M per c3 launch, 0.1308 -> 0.1281 / 1.281 -> 1.344 -- and 137 MB of
 //    scratch writes per 1080p frame reach HBM (WRITE_SIZE 24.9 -> 162 MB): a 2 % gain for six times the
 //    memory traffic;
-//  * 2 or 4 slab bounds in flight per wave in the expansion (RTGS_EXPAND) with that list's free registers:
+//  * 2 or 4 slab bounds in flight per wave in the expansion (Tune::kExpand) with that list's free registers:
 //    0.1289 -> 0.1304 / 0.1307;
 //  * whole frames alternating over two streams on ONE GPU (frame f+1's k_project + k_bin in the shadow of
 //    frame f's k_trace): 0.1468 -> 0.1733 ms per frame at c3, 1.339 -> 1.369 at c5 (two resident k_trace
@@ -110,10 +110,7 @@ namespace {
 #define RTGS_WAVES_PER_SIMD 4   // __launch_bounds__ second argument: caps VGPRs at 512/this
 #endif
 #ifndef RTGS_WAVES_PER_SIMD_MAIN
-#define RTGS_WAVES_PER_SIMD_MAIN 7   // the whole-frame instantiation (no SH, <= 4096 slabs): 72 VGPRs
-#endif
-#ifndef RTGS_WAVES_PER_SIMD_MULTI
-#define RTGS_WAVES_PER_SIMD_MULTI 7   // the same form with frames batched into one launch (kMulti): 72 VGPRs, no scratch, 32 SGPR spills (main: 23)
+#define RTGS_WAVES_PER_SIMD_MAIN 7   // the no-SH forms of scenes up to 4096 slabs (whole frame, list, batched frames): 72 VGPRs
 #endif
 #ifndef RTGS_WAVES_PER_SIMD_SH
 #define RTGS_WAVES_PER_SIMD_SH 5   // the SH variant carries 15 basis values more per lane (c5: 1.54 ms at 5 with 2 gathers in flight, 1.60 at 4 / 4)
@@ -122,9 +119,6 @@ namespace {
 #define RTGS_LOOKAHEAD 1  // big scenes: touch the next candidate's record line one iteration ahead (scalar-cache
 #endif                    // prefetch).  c5 (64 MB of records) 1.74 -> 1.58 ms; c3 (6.4 MB, L2-resident) 0.188 -> 0.192: off there
 
-#ifndef RTGS_CUT_TRAVERSAL
-#define RTGS_CUT_TRAVERSAL 1   // t_cutoff > 0 also ends a tile's traversal (k_trace<..., kCut = true>)
-#endif
 #ifndef RTGS_BINS
 #define RTGS_BINS 1       // per-frame supertile bins of depth-sorted slab lists (k_bin); 0: every tile scans all slab bounds
 #endif
@@ -139,87 +133,47 @@ namespace {
 #define RTGS_SH_STAGE 1   // SH forms of scenes up to 262 k Gaussians: the 16x16 tile's referenced Gaussians' coefficients are
 #endif                    // fetched ONCE per workgroup into LDS and read per lane from there (k_trace, "SH staging"): c3 + SH
                           // 0.2905 -> 0.2617 ms.  0: every lane gathers its entries' coefficients from memory
-#ifndef RTGS_SLAB_ITERS
-#define RTGS_SLAB_ITERS 2
-#endif
-#ifndef RTGS_GROUP
-#define RTGS_GROUP 4
-#endif
-#ifndef RTGS_SLAB_ITERS_BIG
-#define RTGS_SLAB_ITERS_BIG 4
-#endif
-#ifndef RTGS_SLAB_CAP_BIG
-#define RTGS_SLAB_CAP_BIG 2048
-#endif
-#ifndef RTGS_SLABS_PER_WAVE_BIG
-#define RTGS_SLABS_PER_WAVE_BIG 4
-#endif
-#ifndef RTGS_EXPAND
-#define RTGS_EXPAND 1      // c3: 0.185 ms with 1, 0.189 with 2, 0.194 with 4 (registers); c5 does not care
-#endif
-#ifndef RTGS_EXPAND_SPLIT
-#define RTGS_EXPAND_SPLIT 2
-#endif
-#ifndef RTGS_EXPAND_BIG
-#define RTGS_EXPAND_BIG 4
-#endif
-#ifndef RTGS_GROUP_SH
-#define RTGS_GROUP_SH 2   // SH kernels of every size
-#endif
-#ifndef RTGS_GROUP_BIG
-#define RTGS_GROUP_BIG 2   // c5: register pressure of the SH variant decides (8: 1.67 ms, 4: 1.53-1.60, 2: 1.54)
-#endif
-#ifndef RTGS_SLAB_CAP
-#define RTGS_SLAB_CAP 768
-#endif
-#ifndef RTGS_SLABS_PER_WAVE
-#define RTGS_SLABS_PER_WAVE 2
-#endif
+// (round 5: the tuning macros whose sweeps have stood for three rounds -- slab bounds in flight, list capacities, slabs
+// per wave, gathers in flight, the scene size that switches to the two-level scan -- are the constants of Tune below;
+// their measurements are in HISTORY.md)
 constexpr int kSlab = 64;                                 // Gaussians per slab = one wave
 // Batch sizes of the scan / expansion / colour-gather stages.  Measured optimum depends on the
 // number of slabs: c3 (1.6 k slabs) 2/2/4 -> 0.293 ms vs 0.344 with 4/4/8; c5 (15.6 k slabs, SH)
 // 4/4/8 -> 2.67 ms vs 3.11 with 2/2/4 (2.08 with the two-level scan below).  rtgs_trace picks
 // the instantiation by scene size.
-template <bool kBig, int kSplit = 1>
+template <bool kBig>
 struct Tune {
-  static constexpr int kWaves = kWavesPerTile * kSplit;     // waves per workgroup
+  static constexpr int kWaves = kWavesPerTile;              // waves per workgroup
   static constexpr int kBlock = kWaves * kWave;             // threads per workgroup
-  static constexpr int kSlabIters = (kBig ? RTGS_SLAB_ITERS_BIG : RTGS_SLAB_ITERS) / kSplit;  // slab bounds in flight per thread
+  static constexpr int kSlabIters = kBig ? 4 : 2;           // slab bounds in flight per thread
   static constexpr int kSlabStep = kSlabIters * kBlock;     // slabs scanned per barrier
-  static constexpr int kSlabCap = kBig ? RTGS_SLAB_CAP_BIG : RTGS_SLAB_CAP;   // LDS list of surviving slabs
-  static constexpr int kSlabsPerWave = kBig ? RTGS_SLABS_PER_WAVE_BIG : RTGS_SLABS_PER_WAVE;   // slabs one wave expands per batch
+  static constexpr int kSlabCap = kBig ? 2048 : 768;        // LDS list of surviving slabs
+  static constexpr int kSlabsPerWave = kBig ? 4 : 2;        // slabs one wave expands per batch
   // LDS list of surviving Gaussians (indices): kWavesPerTile regions of kSlabsPerWave slabs' worth;
   // the same in both workgroup forms, so that both see the same list order
   static constexpr int kListCap = kSlabsPerWave * kWavesPerTile * kSlab;
-  static constexpr int kGroup = kBig ? RTGS_GROUP_BIG : RTGS_GROUP;   // colour/opacity gathers in flight
+  // colour/opacity gathers in flight (c5: the SH form's register pressure decides -- 8: 1.67 ms, 4: 1.53-1.60, 2: 1.54;
+  // the SH forms of every size keep two)
+  static constexpr int kGroup = kBig ? 2 : 4;
+  static constexpr int kGroupSh = 2;
+  // slabs one wave has in flight in the expansion (c3: 0.185 ms with 1, 0.189 with 2, 0.194 with 4; c5 does not care)
+  static constexpr int kExpand = kBig ? 4 : 1;
   static_assert(kSlabCap >= kSlabStep + 64, "slab list too small");
 };
-#ifndef RTGS_BIG_SLABS
-#define RTGS_BIG_SLABS 4096
-#endif
-constexpr int kBigSceneSlabs = RTGS_BIG_SLABS;   // scenes with more slabs than this use Tune<true>
-#ifndef RTGS_SPLIT_MAX_TILES
-#define RTGS_SPLIT_MAX_TILES 700
-#endif
-constexpr int kSplitMaxTiles = RTGS_SPLIT_MAX_TILES;
-#ifndef RTGS_SUPER
-#define RTGS_SUPER 16
-#endif
+constexpr int kBigSceneSlabs = 4096;   // scenes with more slabs than this (262 k Gaussians) use Tune<true>
 // Tune<true> scans slab bounds in two levels: bounds of kSuper consecutive slabs first, then the
 // slabs of the surviving groups only.  c5 (15.6 k slabs): the flat scan was 27 % of a workgroup's
 // lifetime (every one of 32 400 workgroups streaming 250 KB of bounds through L2); c3 (1.6 k slabs)
 // is faster flat (one barrier less), so Tune<false> keeps the flat scan.
-constexpr int kSuper = RTGS_SUPER;
+constexpr int kSuper = 16;
 // A tile's surviving slabs are visited nearest first (by k_project's depth key) when there are at
 // most kSortMax of them (512 / 1024 for scenes above 262 k Gaussians: as many keys as fit the LDS
 // they borrow; both workgroup forms use the same bound).  In stream (Morton) order near
 // and far Gaussians interleave and nearly EVERY candidate inserts into some lane's list; nearest
 // first, the lists fill with near entries and far candidates are rejected wave-wide: 56 -> 44
 // inserting candidates on c3's central 8x8 tiles (simulated with the oracle; sorting single
-// Gaussians exactly would give 43.5).  Pixels do not depend on the order (see list_insert_par).
-#ifndef RTGS_SORT_MAX
-#define RTGS_SORT_MAX 4096   // capped by the LDS the depth keys can borrow: kListCap floats (512 / 1024)
-#endif
+// Gaussians exactly would give 43.5).  Pixels do not depend on the order (see list_insert2).
+constexpr int kSortMaxAsk = 4096;   // capped by the LDS the depth keys can borrow: kListCap floats (512 / 1024)
 
 constexpr int kBinSupertilesMax = 4096;   // supertile bins the workspace provides for (4 K at 64 px: 2 040), see k_bin
 #ifndef RTGS_TILE_BINS
@@ -248,7 +202,6 @@ struct TraceArgs {
   float* start;
   int32_t start_stride;
   const int32_t* tile_order;
-  int32_t idx_bits;   // kSplit == 2: list entries carry (arrival rank << idx_bits) | index
   const FrameCam* pose;   // optional: camera pose in device memory (only its rotation is used here)
   // per-frame bins (k_bin): depth-sorted slab lists of the supertiles of 2^bin_shift macro-tiles
   const int32_t* bin_count;   // [supertiles], -1 = overflowed: that supertile's tiles scan for themselves
@@ -618,14 +571,11 @@ __global__ __launch_bounds__(kThreads) void k_project(int32_t n, const float* __
 // steps and rank-sorting its survivors -- a quarter of a k_trace workgroup's life at c3.
 // ------------------------------------------------------------------------------------
 constexpr int kBinCapMax = 1024;          // slabs a bin can list; more = overflow, the tiles fall back to scanning
-#ifndef RTGS_BIN_GROUPS
-#define RTGS_BIN_GROUPS 1024   // 16-slab groups a supertile can keep in k_bin<true> (16 k slabs = 1 M Gaussians' worth);
-#endif                         // more = overflow, its tiles scan for themselves.  (4096: 12 KB more LDS, a workgroup per
-                               // CU fewer now that the listed slabs' bounds are kept too: c5 project + bin 63.1 -> 58.6 us)
-#ifndef RTGS_BIN_ITERS
-#define RTGS_BIN_ITERS 8       // slab bounds in flight per thread: c3's 1 563 slabs are ONE step (4: two; 16.3 -> 15.8 us)
-#endif
-constexpr int kBinIters = RTGS_BIN_ITERS;
+// 16-slab groups a supertile can keep in k_bin<true> (16 k slabs = 1 M Gaussians' worth); more = overflow, its tiles scan
+// for themselves.  (4096: 12 KB more LDS, a workgroup per CU fewer now that the listed slabs' bounds are kept too: c5
+// project + bin 63.1 -> 58.6 us)
+constexpr int kBinGroups = 1024;
+constexpr int kBinIters = 8;   // slab bounds in flight per thread: c3's 1 563 slabs are ONE step (4: two; 16.3 -> 15.8 us)
 
 __host__ __device__ inline int bin_stride_of(size_t nslabs) {
   const size_t c = nslabs < (size_t)kBinCapMax ? nslabs : (size_t)kBinCapMax;
@@ -651,7 +601,7 @@ __global__ __launch_bounds__(256) void k_bin(int32_t nslabs, const float4* __res
   __shared__ float4 s_bb[RTGS_TILE_BINS ? kBinCapMax : 1];      // bounds of the listed slabs (list order)
   __shared__ int s_perm[RTGS_TILE_BINS ? kBinCapMax : 1];        // sorted position -> list position
   __shared__ int s_wc[2][4];
-  constexpr int kGrpCap = RTGS_BIN_GROUPS;
+  constexpr int kGrpCap = kBinGroups;
   __shared__ int s_grp[kGroups ? kGrpCap : 1];
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
   const int st = blockIdx.x;
@@ -838,32 +788,12 @@ __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballo
 // keep their ARRIVAL order, and k_trace makes that order a function of the tile alone (slabs
 // nearest first, lanes in index order): the same in every instantiation and for every sharding.
 //
-// Insertion, chain-free form (default): the new key is compared with all 16 ORIGINAL slots at
-// once (independent compares; the results are monotone because the list is sorted), then every
-// slot picks its own value, its left neighbour's or the new element with two selects per field.
-// 112 VALU but no level depends on the previous one.  Measured against the alternatives on c3
-// (full frame / one-eighth shard): this 0.293 ms / 66 us; serial bubble with v_cmpx + v_swap_b32
-// under EXEC below (64 VALU, ~64 cycles of EXEC round trip per level even on an idle SIMD)
-// 0.301 / 85; select bubble on 64-bit (t1,index) keys 0.374; select bubble on 32-bit keys 0.372
-// / 94; v_med3_u32 for the keys 0.313 / 64; LDS append lists behind a front-to-back sort 1.21.
-template <int kK>
-__device__ __forceinline__ void list_insert_par(unsigned (&kt)[kK], unsigned (&ki)[kK], float (&kw)[kK],
-                                                unsigned tn, unsigned in, float wn) {
-  bool lt[kK];
-#pragma unroll
-  for (int k = 0; k < kK; ++k) lt[k] = tn < kt[k];
-#pragma unroll
-  for (int k = kK - 1; k > 0; --k) {
-    kt[k] = lt[k - 1] ? kt[k - 1] : (lt[k] ? tn : kt[k]);
-    ki[k] = lt[k - 1] ? ki[k - 1] : (lt[k] ? in : ki[k]);
-    kw[k] = lt[k - 1] ? kw[k - 1] : (lt[k] ? wn : kw[k]);
-  }
-  kt[0] = lt[0] ? tn : kt[0];
-  ki[0] = lt[0] ? in : ki[0];
-  kw[0] = lt[0] ? wn : kw[0];
-}
+// Insertion is chain-free: the new key is compared with all 16 ORIGINAL slots at once (independent compares; the
+// results are monotone because the list is sorted), then every slot picks its own value, its left neighbour's or the
+// new element.  (Round 1 measured the alternatives on c3: serial bubble with v_cmpx + v_swap_b32 0.301 ms vs 0.293,
+// select bubbles on 64- / 32-bit keys 0.374 / 0.372, LDS append lists behind a front-to-back sort 1.21: HISTORY.md.)
 
-// The one-wave K = 16 form keeps only TWO register arrays per lane: the t1 bits and a payload
+// The list keeps only TWO register arrays per lane: the t1 bits and a payload
 // (index << 4 | slot).  The third field, the exponent delta/(4A), lives in LDS in one of the lane's
 // 16 slots; the slots of a list are a permutation of 0..15 (slot k at start), and a new entry
 // takes the slot of the entry that falls off the end, so the exponent never moves: 16 compares +
@@ -948,21 +878,6 @@ __device__ __forceinline__ unsigned pair_eval(const float4* __restrict__ rec, co
   return (hit && t1 > start && __float_as_uint(t1) < 0x7F800000u) ? __float_as_uint(t1) : ~0u;
 }
 
-// kK = list length: RTGS_MAX_DEPTH, or 1 for single-peel calls (the reference viewer's one
-// sample_step per frame), where the list degenerates to "the nearest hit so far".
-//
-// kSplit = 2 (shards that are a single resident round, see rtgs_trace): TWO waves per 8x8 tile.
-// Both walk the same survivor stream and take alternate candidates, so the critical path of a
-// heavy tile halves; at the end the second wave hands its list over through LDS and the first
-// merges (bitonic, ordered by (t1, index) = arrival order) and composites.  Same pixels bit for
-// bit as kSplit = 1.
-// kCut (t_cutoff > 0 only): the transmittance cut-off also ends a tile's TRAVERSAL.  Before each
-// chunk of 64 candidates the wave forms, per ray, the attenuation through the list entries nearer
-// than every candidate still to come in this round (suffix minimum of k_project's distance bounds
-// over the remaining chunks: those entries are final in value and position), exactly as the
-// compositing loop will; if every ray of the tile is below the cut-off there -- or already holds
-// `depth` final entries -- a wave ballot skips the rest of the round.  Exact: a terminated ray
-// composites nothing behind those entries, so the image equals the compositing-only cut-off's.
 // colour += sum_q Y_q * sh_q (gaussian.py:165-181) in explicit fma chains: the single-entry paths (listed peel, tie
 // fix-up) and the list forms of scenes up to 262 k Gaussians; the 1 M-Gaussian list forms keep `+=` (within 1 ulp per term of this)
 __device__ __forceinline__ void sh_add(float4& co, const float (&Y)[RTGS_SH_COEFFS], const float* __restrict__ sp) {
@@ -978,11 +893,15 @@ __device__ __forceinline__ void sh_add(float4& co, const float (&Y)[RTGS_SH_COEF
 // (an instantiation of its own: as a run-time branch it cost the main one five spilled VGPRs).
 // kMulti (rtgs_shard_frames): frames batched into one launch, blockIdx.y = frame (an instantiation of its own: the
 // per-frame pointer offsets cost the 72-VGPR main form 20 spilled VGPRs when they were unconditional).
-template <bool kHasSh, bool kBig, int kK, int kSplit, bool kCut = false, bool kList = false, bool kMulti = false>
-__global__ __launch_bounds__(kTraceBlock * kSplit,
-                             kHasSh ? (kBig && kSplit == 1 ? RTGS_WAVES_PER_SIMD_SH : RTGS_WAVES_PER_SIMD)
-                                    : (!kBig && kSplit == 1 && kK == RTGS_MAX_DEPTH ? (kMulti ? RTGS_WAVES_PER_SIMD_MULTI : RTGS_WAVES_PER_SIMD_MAIN)
-                                                                                    : RTGS_WAVES_PER_SIMD)) void k_trace(const TraceArgs a,
+// Round 5 retired three forms the measurements had left without a case (HISTORY.md): two waves per 8x8 tile (the "split" form:
+// <= 5 % for a LONE launch below 700 tiles, nothing with two frames in flight, and batched launches have no lone small
+// launch), the traversal cut of t_cutoff (never paid on any scene tried; the compositing cut stays) and the
+// one-entry list (kK = 1: single peels go through the peel lists, the fall-backs through this kernel with depth = 1).
+template <bool kHasSh, bool kBig, bool kList = false, bool kMulti = false>
+__global__ __launch_bounds__(kTraceBlock,
+                             kHasSh ? (kBig ? RTGS_WAVES_PER_SIMD_SH : RTGS_WAVES_PER_SIMD)
+                                    : (!kBig ? RTGS_WAVES_PER_SIMD_MAIN
+                                             : RTGS_WAVES_PER_SIMD)) void k_trace(const TraceArgs a,
                                                           const float4* __restrict__ bbox,
                                                           const float4* __restrict__ slab_bbox,
                                                           const float4* __restrict__ super_bbox,
@@ -991,28 +910,24 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
                                                           const float* __restrict__ tmin,
                                                           const float4* __restrict__ colop,
                                                           const float* __restrict__ sh) {
-  static_assert(kSplit == 1 || kSplit == 2, "one or two waves per 8x8 tile");
-  using TN = Tune<kBig, kSplit>;
+  constexpr int kK = RTGS_MAX_DEPTH;   // entries kept per ray
+  using TN = Tune<kBig>;
   constexpr int kSlabIters = TN::kSlabIters, kSlabStep = TN::kSlabStep, kSlabCap = TN::kSlabCap,
                 kSlabsPerWave = TN::kSlabsPerWave, kListCap = TN::kListCap,
                 kWaves = TN::kWaves, kBlock = TN::kBlock;
-  // the survivor list and (kSplit == 2) the list hand-over share one LDS pool: the hand-over
+  // the survivor list's LDS pool
   // happens after the last barrier of the candidate loop
   // (hand-over in two halves of kK/2 entries x {t1, payload}: 16 KB instead of 32)
-  constexpr int kMergeWords = kSplit == 2 ? kWavesPerTile * 2 * (kK / 2) * kWave : 0;
   constexpr int kListF4 = kListCap / 4;          // int indices; the 16-B bounds are re-read (L1) by the wave test
-  constexpr int kPoolF4 = kListF4 > kMergeWords / 4 ? kListF4 : kMergeWords / 4;
+  constexpr int kPoolF4 = kListF4;
   __shared__ float4 s_pool[kPoolF4];
   int* const s_idx = reinterpret_cast<int*>(s_pool);
   // exponents of the list entries, [slot][thread]: conflict-free whatever slots the lanes use
-  constexpr bool kLdsW = kK == RTGS_MAX_DEPTH;
-  static_assert(!kLdsW || kK == 16, "the payload keeps the slot in 4 bits");
-  static_assert(kLdsW || kSplit == 1, "the two-wave form exists for the full list only");
-  // payload = entry << kSlotBits | slot field; two-wave form: one more bit says whose LDS column
-  // (this wave's or the helper's) the slot is in, and the entry carries the arrival rank on top
-  constexpr int kSlotBits = kSplit == 2 ? 5 : 4;
+  static_assert(kK == 16, "the payload keeps the slot in 4 bits");
+  // payload = entry << kSlotBits | slot field
+  constexpr int kSlotBits = 4;
   constexpr unsigned kSlotMask = (1u << kSlotBits) - 1u;
-  __shared__ float s_w[kLdsW ? kK * kBlock : 1];
+  __shared__ float s_w[kK * kBlock];
   // surviving slab ids: 16 bits are enough below kBigSceneSlabs (4 096) slabs
   using SlabId = typename std::conditional<kBig, int, unsigned short>::type;
   static_assert(kBig || kBigSceneSlabs <= 65536, "slab ids of small scenes are stored in 16 bits");
@@ -1027,7 +942,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   // a tile's last round of expansion is behind its barrier.  Not for the 1 M-Gaussian form (built, with colour + opacity
   // staged too and 80 slots = what four workgroups per CU leave: c5 1.304 -> 1.459 ms; its tiles name 66.8 distinct
   // Gaussians on average, 42 % of them more than 80, and a wave with one slot-less lane runs both sources).
-  constexpr bool kStage = RTGS_SH_STAGE != 0 && kHasSh && !kBig && kK == RTGS_MAX_DEPTH && kSplit == 1 && !kList;
+  constexpr bool kStage = RTGS_SH_STAGE != 0 && kHasSh && !kBig && !kList;
   constexpr int kStageSlots = 96, kStageStride = 52;
   constexpr unsigned kAbs = 1u << 31;     // kStage payloads: the id field is a Gaussian index (else: a survivor-list slot)
   constexpr int kStageBytes = kStageSlots * kStageStride * (int)sizeof(float);
@@ -1045,13 +960,13 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   __shared__ int s_nref[kStage ? 1 + kWavesPerTile : 1];
   // depth keys of the first kSortMax listed slabs: only alive between the scan and the sort, when
   // the survivor pool is idle (every batch ends with a barrier) -- they share its LDS
-  constexpr int kSortMax = RTGS_SORT_MAX < kListCap ? RTGS_SORT_MAX : kListCap;   // kListCap floats fit the pool
+  constexpr int kSortMax = kSortMaxAsk < kListCap ? kSortMaxAsk : kListCap;   // kListCap floats fit the pool
   float* const s_skey = reinterpret_cast<float*>(s_pool);
   __shared__ int s_wcnt[2][kWaves];
   constexpr int kRegions = kWavesPerTile;            // expander waves = regions of the survivor list
   constexpr int kRegionCap = kListCap / kRegions;
   // slabs one wave has in flight: more only pay where latency counts (the two-wave form's small launches)
-  constexpr int kExpand = kBig ? RTGS_EXPAND_BIG : (kSplit == 2 ? RTGS_EXPAND_SPLIT : RTGS_EXPAND);
+  constexpr int kExpand = TN::kExpand;
   static_assert(kRegionCap >= kSlab, "a region must hold one whole slab");
   __shared__ int s_rcnt[kRegions], s_rmore[kRegions];
   constexpr int kSuperStep = kSlabIters * kBlock;   // slab groups scanned per outer step
@@ -1066,7 +981,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tile bounds stay in SGPRs
   // frames batched into one launch (rtgs_shard_frames): blockIdx.y = frame; everything per-frame lies
   // blockIdx.y * frame_stride bytes behind frame 0's (zero offset for the one-frame launches)
-  static_assert(!kMulti || (kK == RTGS_MAX_DEPTH && kSplit == 1 && !kCut && !kList), "batched frames: the plain full-list form only");
+  static_assert(!(kMulti && kList), "batched frames composite: the list form is one frame per launch");
   const int32_t* f_bin_count = a.bin_count;
   const int32_t* f_bin_list = a.bin_list;
   const int32_t* f_tile_bin = a.tile_bin;
@@ -1085,7 +1000,6 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
   const int mi0 = (tile % a.tiles_x) * kTile;
   const int mj0 = (tile / a.tiles_x) * kTile;
   const int sub = wave % kWavesPerTile;    // which 8x8 tile of the macro-tile
-  const int role = __builtin_amdgcn_readfirstlane(wave / kWavesPerTile);   // kSplit == 2: 0 keeps the list, 1 helps
   const int wi0 = mi0 + (sub % kWavesX) * kWaveTile;
   const int wj0 = mj0 + (sub / kWavesX) * kWaveTile;
   const int pi = wi0 + (lane >> 3);
@@ -1116,28 +1030,17 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
 
   unsigned key[kK], kidx[kK];
   constexpr unsigned kEmpty = 0x7F800000u;  // +inf
-  constexpr int kWn = kLdsW ? 1 : kK;
-  float wexp[kWn];
 #pragma unroll
   for (int k = 0; k < kK; ++k) {
     key[k] = kEmpty;
-    kidx[k] = kLdsW ? (unsigned)k | ((unsigned)role << 4) : 0u;   // kLdsW: payload = entry << kSlotBits | slot
+    kidx[k] = (unsigned)k;   // payload = entry << kSlotBits | slot: the slots of a list are a permutation of 0..15
   }
-#pragma unroll
-  for (int k = 0; k < kWn; ++k) wexp[k] = 0.f;
   [[maybe_unused]] float* const s_wl = s_w + tid;
   constexpr bool kHorizon = RTGS_HORIZON != 0 && kK == RTGS_MAX_DEPTH;
-  static_assert(!kCut || (kSplit == 1 && kK == RTGS_MAX_DEPTH), "traversal cut: one-wave full-list form only");
-  static_assert(!kList || (kSplit == 1 && kK == RTGS_MAX_DEPTH && !kCut), "peel lists: one-wave full-list form only");
   constexpr int kChunksMax = kListCap / kWave;
-  __shared__ float s_smin[kCut ? kWaves * kChunksMax : 1];   // per wave: suffix minima of the chunks' distance bounds
-  [[maybe_unused]] float T_in = 1.f;                            // attenuation this call starts from
-  if constexpr (kCut) {
-    if ((a.flags & RTGS_TRACE_RESUME) && in_img) T_in = a.att[(size_t)pi * a.height + pj];
-  }
   constexpr bool kLookahead = RTGS_LOOKAHEAD == 2 || (RTGS_LOOKAHEAD == 1 && kBig);
   static_assert(RTGS_TIER > 0 && RTGS_TIER < RTGS_MAX_DEPTH, "the tier boundary lies inside the list");
-  constexpr int kTier = kLdsW ? RTGS_TIER : kK;
+  constexpr int kTier = RTGS_TIER;
   [[maybe_unused]] bool tier_short = kTier < kK;   // wave-uniform: slot kTier-1 still empty in every lane
 
   // set bits of a wave mask below this lane: v_mbcnt_lo/hi straight from the SGPR pair
@@ -1164,7 +1067,6 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
     for (int q = 0; q < kListCap / kBlock; ++q) s_ref[q * kBlock + tid] = 0;   // (ordered before any mark by the scan's barriers)
   }
   int scnt = 0;  // surviving slabs listed so far: identical in every thread
-  int turn = 0;  // kSplit == 2: candidates of this 8x8 tile seen so far (wave-uniform)
   // this tile's supertile bin (k_bin), if the frame has bins and the bin did not overflow
   const int bin_at = ((tile / a.tiles_x) >> a.bin_shift) * a.bin_sx + ((tile % a.tiles_x) >> a.bin_shift);
   const int bin_n = f_bin_count ? __builtin_amdgcn_readfirstlane(f_bin_count[bin_at]) : -1;
@@ -1404,61 +1306,10 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
         [[maybe_unused]] int ls, lsnext = 0;
         float4 wb, wbnext = make_float4(kInf, kInf, -kInf, -kInf);
         float tm, tmnext = 0.f;
-        // (only rounds of at least kCutMinChunks chunks are worth it: the check costs about as much as
-        // five candidates, and c3-sized tiles see two or three chunks in all)
-        constexpr int kCutMinChunks = 4;
-        [[maybe_unused]] const bool cut_round = kCut && total > (kCutMinChunks - 1) * kWave;
-        if (cut_round) {
-          // suffix minima of the distance bounds over this round's chunks (bounds are >= 0: their
-          // bits order like the floats)
-          unsigned run = kEmpty;
-          for (int c = ((total - 1) / kWave) * kWave; c >= 0; c -= kWave) {
-            int gq, lq; float4 wq; float tq;
-            fetch(c, gq, wq, tq, lq);
-            run = min(run, wave_umin(gq >= 0 ? __float_as_uint(tq) : kEmpty));
-            if (lane == 0) s_smin[wave * kChunksMax + c / kWave] = __uint_as_float(run);
-          }
-        }
         fetch(0, g, wb, tm, ls);
         for (int c = 0; c < total; c += kWave) {
-          if (cut_round && c > 0 && (c & kWave) == 0 && total - c > kWave) {   // every other chunk
-            // attenuation through the entries nearer than everything still to come, as the
-            // compositing loop will form it (same operations in the same order)
-            const unsigned bnd = __float_as_uint(__builtin_amdgcn_readfirstlane(s_smin[wave * kChunksMax + c / kWave]));
-            float Tp = T_in;
-            int nh = 0;
-            unsigned prev = 0u;
-#pragma unroll
-            for (int k = 0; k < kK; ++k) {
-              const unsigned tb = key[k];
-              const bool fin = tb < bnd;                       // final: nothing to come can precede it
-              const bool valid = fin && tb != prev && nh < a.depth;
-              prev = tb;
-              if (wave_any(valid && !(Tp < a.t_cutoff))) {
-                unsigned gk = kidx[k] >> kSlotBits;
-                if constexpr (kStage) gk = (kidx[k] & kAbs) ? (gk & 0x3FFFFFFu) : (unsigned)s_idx[gk & 0x3FFFFFFu];
-                const float op = fin ? colop[gk].w : 0.f;
-                const float alpha = op * exp_m3(s_wl[(kidx[k] & 15u) * kBlock]);
-                if (valid && !(Tp < a.t_cutoff)) { Tp *= 1.0f - alpha; ++nh; }
-              }
-            }
-            const bool dead = !in_img || Tp < a.t_cutoff || nh == a.depth;
-            if (!wave_any(!dead)) break;                       // the ballot: nothing left for this tile here
-          }
           const bool pass = wb.x <= wXhi && wb.z >= wXlo && wb.y <= wYhi && wb.w >= wYlo;
           unsigned long long m = __ballot(pass);
-          [[maybe_unused]] const unsigned long long m_all = m;
-          [[maybe_unused]] const int turn0 = turn;
-          if constexpr (kSplit == 2) {
-            // keep every other candidate: prefix parity of the mask marks the 1st, 3rd, ... set
-            // bit; `turn` carries the parity over from the previous chunks
-            unsigned long long par_m = m ^ (m << 1);
-            par_m ^= par_m << 2; par_m ^= par_m << 4; par_m ^= par_m << 8;
-            par_m ^= par_m << 16; par_m ^= par_m << 32;
-            const bool odd_first = ((turn ^ role) & 1) == 0;   // this wave takes the 1st, 3rd, ...
-            turn += __popcll(m);
-            m &= odd_first ? par_m : ~par_m;
-          }
           if constexpr (kHorizon) {
             // Horizon: once every ray of the tile holds kK entries, a candidate whose distance bound
             // lies at or beyond the farthest of their last entries cannot enter any list.  One wave
@@ -1576,13 +1427,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
 #else
               unsigned entry = (unsigned)gi;
               if constexpr (kStage) entry = (unsigned)__builtin_amdgcn_readlane(ls, b);   // the survivor-list slot, see kStage
-              if constexpr (kSplit == 2) {
-                // arrival rank of this candidate in the tile's stream, above the index bits: the
-                // merge then orders equal t1 exactly as the one-wave form's arrival order does
-                const unsigned rank = (unsigned)(turn0 + __popcll(m_all & ((1ull << b) - 1ull)));
-                entry |= rank << a.idx_bits;
-              }
-              if constexpr (kLdsW) {
+              {
                 // the new entry takes the exponent slot of the entry that falls off the end
                 const unsigned slot = (tier_short ? kidx[kTier - 1] : kidx[kK - 1]) & kSlotMask;
                 const unsigned pn = (entry << kSlotBits) | slot;
@@ -1604,8 +1449,6 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
                 if constexpr (kTier < kK) {
                   if (tier_short) tier_short = !wave_any(key[kTier - 1] < kEmpty);
                 }
-              } else {
-                list_insert_par(key, kidx, wexp, kn, entry, wn);
               }
 #endif
 #if RTGS_STAMPS
@@ -1633,7 +1476,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
               kidx[k] = kAbs | ((unsigned)s_idx[(kidx[k] >> kSlotBits) & 0x3FFFFFFu] << kSlotBits) | (kidx[k] & kSlotMask);
         }
       }
-      if (kSplit == 2 || more || !last) __syncthreads();
+      if (more || !last) __syncthreads();
 #if RTGS_STAMPS
       t_bar += __builtin_amdgcn_s_memtime() - t_mark;
 #endif
@@ -1645,60 +1488,6 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
 
 #if RTGS_STAMPS
   t_mark = __builtin_amdgcn_s_memtime();
-#endif
-  if constexpr (kSplit == 2) {
-    // ---- hand the helper wave's list over and merge: min(A[i], B[K-1-i]) is the bitonic
-    // sequence of the K smallest of both; log2(K) half-cleaners sort it.  Order = (t1, arrival
-    // rank), the rank riding above the index bits of the entries (at least 10 bits: the host only
-    // picks this form for n <= 131072; exact while a tile's stream has fewer than 1024 candidates,
-    // beyond that only the order of exact ties is lost).
-    constexpr int kH = kK / 2;
-    unsigned* const mp = reinterpret_cast<unsigned*>(s_pool) + sub * (2 * kH * kWave) + lane;
-    // min(A[i], B[K-1-i]) for i < K/2 needs the helper's upper half, for i >= K/2 its lower half
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      if (half == 1) __syncthreads();     // the first half has been read
-      if (role == 1) {
-#pragma unroll
-        for (int k = 0; k < kH; ++k) {
-          const int src = half == 0 ? kH + k : k;
-          mp[(0 * kH + k) * kWave] = key[src];
-          mp[(1 * kH + k) * kWave] = kidx[src];
-        }
-      }
-      __syncthreads();
-      if (role == 0) {
-#pragma unroll
-        for (int ii = 0; ii < kH; ++ii) {
-          const int i = half * kH + ii;          // this wave's slot
-          const int j = kK - 1 - i;              // the helper's slot it meets
-          const int k = half == 0 ? j - kH : j;  // where that slot sits in the hand-over block
-          const unsigned tb = mp[(0 * kH + k) * kWave], ib = mp[(1 * kH + k) * kWave];
-          const bool lt = tb < key[i] || (tb == key[i] && ib < kidx[i]);
-          key[i] = lt ? tb : key[i];
-          kidx[i] = lt ? ib : kidx[i];
-        }
-      }
-    }
-    if (role == 1) return;
-#pragma unroll
-    for (int d = kK / 2; d > 0; d >>= 1) {
-#pragma unroll
-      for (int i = 0; i < kK; ++i) {
-        if ((i & d) == 0) {
-          const int j = i + d;
-          const bool sw = key[j] < key[i] || (key[j] == key[i] && kidx[j] < kidx[i]);
-          const unsigned t0 = key[i], i0 = kidx[i];
-          key[i] = sw ? key[j] : t0;   key[j] = sw ? t0 : key[j];
-          kidx[i] = sw ? kidx[j] : i0; kidx[j] = sw ? i0 : kidx[j];
-        }
-      }
-    }
-  }
-
-#if RTGS_STAMPS
-  st[3] = __builtin_amdgcn_s_memtime();
-  t_merge = st[3] - t_mark;
 #endif
   // ---- front-to-back compositing of the sorted list (ray_tracer.py:88-104) ----
   // The pixel's coordinates and linear index are formed again from the lane number (laundered, so
@@ -1901,13 +1690,13 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
     const float in = 1.0f / sqrtf(wx * wx + wy * wy + wz * wz);  // gaussian.py:200
     sh_basis(wx * in, wy * in, wz * in, Ysh);
   }
-  [[maybe_unused]] const unsigned idx_mask = kSplit == 2 ? (1u << ea->idx_bits) - 1u : (kStage ? 0x3FFFFu : ~0u);
+  [[maybe_unused]] const unsigned idx_mask = kStage ? 0x3FFFFu : ~0u;
   int nhit = 0;
   float last_t = 0.f;
   unsigned prev_tbits = 0u;
   // colour/opacity gathers issued together; the SH variants carry 15 basis values per lane and keep
   // two in flight whatever the scene size (four spilled 56 VGPRs in the <= 4096-slab SH kernel)
-  constexpr int kGroupN = kHasSh && TN::kGroup > RTGS_GROUP_SH ? RTGS_GROUP_SH : TN::kGroup;
+  constexpr int kGroupN = kHasSh && TN::kGroup > TN::kGroupSh ? TN::kGroupSh : TN::kGroup;
   constexpr int kGroup = kGroupN < kK ? kGroupN : kK;
   bool done = false;
 #pragma unroll
@@ -1923,18 +1712,18 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
     for (int j = 0; j < kGroup; ++j) {
       const int k = k0 + j;
       const unsigned tb = key[k];
-      const unsigned gi = kLdsW ? (kidx[k] >> kSlotBits) & idx_mask : kidx[k];
+      const unsigned gi = (kidx[k] >> kSlotBits) & idx_mask;
       cog[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (tb < kEmpty) cog[j] = colop[gi];
-      // the exponent: slot (kidx & 15) of this lane's column, or of the helper wave's (bit 4)
-      if constexpr (kLdsW) wl[j] = s_wl[(kidx[k] & 15u) * kBlock + (kSplit == 2 ? ((kidx[k] >> 4) & 1u) * kTraceBlock : 0u)];
+      // the exponent: slot (kidx & 15) of this lane's column
+      wl[j] = s_wl[(kidx[k] & 15u) * kBlock];
     }
 #pragma unroll
     for (int j = 0; j < kGroup; ++j) {
       const int k = k0 + j;
       if (!done) {
         const unsigned tbits = key[k];
-        const unsigned gi = kLdsW ? (kidx[k] >> kSlotBits) & idx_mask : kidx[k];
+        const unsigned gi = (kidx[k] >> kSlotBits) & idx_mask;
         // an exact repeat of the previous entry distance is what the reference's strict
         // `t1 > ray.start` drops (scene.py:433 after ray_tracer.py:101)
         const bool valid = tbits < kEmpty && tbits != prev_tbits && nhit < ea->depth;
@@ -2003,7 +1792,7 @@ __global__ __launch_bounds__(kTraceBlock * kSplit,
           }
         }
         float wk;
-        if constexpr (kLdsW) wk = wl[j]; else wk = wexp[k];
+        wk = wl[j];
         const float alpha = co.w * exp_m3(wk);  // == exp(-d^T S^-1 d) at the chord midpoint
         if (live) {
           const float wa = T * alpha;
@@ -2262,10 +2051,7 @@ static size_t bins_bytes(size_t nslabs, size_t tiles) {
 
 // Bins pay once a tile's own scan is more than one step (k_bin is one more launch, ~3.5 us): c2's
 // 157 slabs are faster without (0.0486 vs 0.0518 ms per frame), c3's 1 563 and c5's 15 625 with.
-#ifndef RTGS_BINS_MIN_SLABS
-#define RTGS_BINS_MIN_SLABS 513
-#endif
-static bool use_bins(int nslabs) { return RTGS_BINS != 0 && nslabs >= RTGS_BINS_MIN_SLABS; }
+static bool use_bins(int nslabs) { return RTGS_BINS != 0 && nslabs >= 513; }
 
 struct BinGeom { int shift, sx, supertiles; };
 // smallest supertile of 2^shift x 2^shift macro-tiles (64 px and up) that covers the frame with <= kBinSupertilesMax bins
@@ -2510,9 +2296,7 @@ static int trace_impl(const RtgsScene* scene, const RtgsCamera* cam, const RtgsT
                       int32_t projected, int32_t tile_limit, rtgs_stream_t stream, void* lists = nullptr,
                       int32_t frames = 1, size_t frame_stride = 0, size_t out_stride = 0, const FrameCam* pose0 = nullptr) {
   if (!params || (!sample_buf && !lists)) return RTGS_EINVAL;
-  if (frames > 1 && (lists || attenuation_buf || ray_start || params->depth > RTGS_MAX_DEPTH || params->depth < 2 ||
-                     params->t_cutoff > 0.f))
-    return RTGS_EINVAL;     // (rtgs_shard_frames only batches what the plain full-list form renders)
+  if (frames > 1 && (lists || attenuation_buf || ray_start || params->depth > RTGS_MAX_DEPTH)) return RTGS_EINVAL;
   if (int rc = validate(scene, cam, workspace, workspace_bytes)) return rc;
   if (params->depth < 1) return RTGS_EDEPTH;
   if (params->depth > RTGS_MAX_DEPTH && !lists) {
@@ -2610,41 +2394,21 @@ static int trace_impl(const RtgsScene* scene, const RtgsCamera* cam, const RtgsT
     const PeelLists pl = peel_lists_of(lists, cam->width, cam->height);
     a.list_cnt = pl.cnt; a.list_idx = pl.idx; a.list_w = pl.w; a.list_t = pl.t;
   }
-  a.idx_bits = 1;
-  while (a.idx_bits < 31 && (1u << a.idx_bits) < (uint32_t)scene->n) ++a.idx_bits;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool big = (scene->n + kSlab - 1) / kSlab > kBigSceneSlabs;
   const float* sh = scene->sh;
-  // Two waves per 8x8 tile when the launch is at most kSplitMaxTiles workgroups (a shard that is
-  // about one resident round: its time is the critical path of its heaviest tile, and halving
-  // that is worth the extra merge); callers can force either form.
-  bool split = local <= kSplitMaxTiles;
-  if (params->flags & RTGS_TRACE_SPLIT_ON) split = true;
-  if (params->flags & RTGS_TRACE_SPLIT_OFF) split = false;
-  if (params->depth == 1) split = false;
-  const bool k1 = params->depth == 1 && !lists;   // (the list form always keeps RTGS_MAX_DEPTH entries)
-  // the cut-off's traversal cut has its own instantiation of the one-wave full-list form
-  const bool cut = RTGS_CUT_TRAVERSAL != 0 && params->t_cutoff > 0.f && params->depth > 1 && !lists;
-  if (a.idx_bits > 17) split = false;   // two-wave entries: rank | index | 5 slot bits in 32; 10 rank bits need n <= 131072
-#define RTGS_LAUNCH(HAS_SH, BIG, K, SPLIT)                                                         \
-  hipLaunchKernelGGL((k_trace<HAS_SH, BIG, K, SPLIT>), dim3(local), dim3(kTraceBlock * SPLIT), 0, s, a, \
-                     bbox, slab_bbox, super_bbox, rec, tail, tmin, colop, sh)
 #define RTGS_LAUNCH_K(HAS_SH, BIG)                                                  \
   do {                                                                              \
-    if (lists) hipLaunchKernelGGL((k_trace<HAS_SH, BIG, RTGS_MAX_DEPTH, 1, false, true>), dim3(local), dim3(kTraceBlock), 0, s, a, \
+    if (lists) hipLaunchKernelGGL((k_trace<HAS_SH, BIG, true, false>), dim3(local), dim3(kTraceBlock), 0, s, a, \
                                   bbox, slab_bbox, super_bbox, rec, tail, tmin, colop, sh);                              \
-    else if (cut) hipLaunchKernelGGL((k_trace<HAS_SH, BIG, RTGS_MAX_DEPTH, 1, true>), dim3(local), dim3(kTraceBlock), 0, s, a, \
-                                bbox, slab_bbox, super_bbox, rec, tail, tmin, colop, sh);                                \
-    else if (frames > 1) hipLaunchKernelGGL((k_trace<HAS_SH, BIG, RTGS_MAX_DEPTH, 1, false, false, true>), dim3(local, frames), dim3(kTraceBlock), 0, s, a, \
+    else if (frames > 1) hipLaunchKernelGGL((k_trace<HAS_SH, BIG, false, true>), dim3(local, frames), dim3(kTraceBlock), 0, s, a, \
                                             bbox, slab_bbox, super_bbox, rec, tail, tmin, colop, sh);                    \
-    else if (k1) RTGS_LAUNCH(HAS_SH, BIG, 1, 1);                                    \
-    else if (split) RTGS_LAUNCH(HAS_SH, BIG, RTGS_MAX_DEPTH, 2);                    \
-    else RTGS_LAUNCH(HAS_SH, BIG, RTGS_MAX_DEPTH, 1);                               \
+    else hipLaunchKernelGGL((k_trace<HAS_SH, BIG, false, false>), dim3(local), dim3(kTraceBlock), 0, s, a, \
+                            bbox, slab_bbox, super_bbox, rec, tail, tmin, colop, sh);                                    \
   } while (0)
   if (sh) { if (big) RTGS_LAUNCH_K(true, true); else RTGS_LAUNCH_K(true, false); }
   else    { if (big) RTGS_LAUNCH_K(false, true); else RTGS_LAUNCH_K(false, false); }
 #undef RTGS_LAUNCH_K
-#undef RTGS_LAUNCH
   return check_launch();
 }
 
@@ -2677,7 +2441,7 @@ int rtgs_trace_lists(const RtgsScene* scene, const RtgsCamera* cam, const int32_
   p.t_cutoff = 0.f;
   p.tile_first = 0;
   p.tile_step = 1;
-  p.flags = RTGS_TRACE_SPLIT_OFF;
+  p.flags = 0;
   p.tile_order = tile_order;
   p.tile_list = nullptr;
   p.tile_count = 0;
@@ -2825,7 +2589,7 @@ int rtgs_shard_frames(const RtgsScene* scene, const RtgsCamera* cams, int32_t n_
   int32_t merge = 1;
   size_t region = 0, pose_off = 0;
   if (!empty_share && n_frames > 1 && scene && params && !attenuation_bufs && !ray_starts && params->depth <= RTGS_MAX_DEPTH &&
-      params->depth >= 2 && !(params->t_cutoff > 0.f) && cams[0].width > 0 && cams[0].height > 0) {
+      cams[0].width > 0 && cams[0].height > 0) {
     region = frame_region_bytes(scene->n, cams[0].width, cams[0].height);
     pose_off = frame_pose_offset(scene->n, cams[0].width, cams[0].height);
     const size_t room = region ? workspace_bytes / region : 0;

@@ -22,8 +22,7 @@ SH_COEFFS = 15
 TRACE_RESUME = 1
 TRACE_ACCUMULATE = 2
 TRACE_COMPACT = 4
-TRACE_SPLIT_ON = 8     # scheduling only: force / forbid two waves per 8x8 tile
-TRACE_SPLIT_OFF = 16
+# (8 and 16 were the two-waves-per-tile form's switches up to ABI v6: retired, the bits are ignored)
 TRACE_TILE_LIST = 32   # the shard is RtgsTraceParams.tile_list / tile_count (an empty list renders nothing)
 TRACE_REGION = 64      # the shard lies inside RtgsTraceParams.region: its projection skips what cannot reach it
 TRACE_BINS_ON = 128    # scheduling only: force / forbid the per-frame slab bins for the call's own projection

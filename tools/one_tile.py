@@ -17,10 +17,10 @@ total = tx * ((cfg.height + T - 1) // T)
 b.project()
 for (ti, tj) in [(60, 33), (46, 44), (10, 5), (60, 60)]:
     tile = tj * tx + ti
-    for split in (0, 1):
+    for split in (0,):
         compact = b.alloc(1, T, T, 3)
         stamps = torch.zeros((1, 14), dtype=torch.int64, device="cuda")
-        params = nat.RtgsTraceParams(cfg.depth, 0.0, tile, total, nat.TRACE_COMPACT | (nat.TRACE_SPLIT_ON if split else nat.TRACE_SPLIT_OFF))
+        params = nat.RtgsTraceParams(cfg.depth, 0.0, tile, total, nat.TRACE_COMPACT)
         for _ in range(3):
             nat.check(nat.lib().rtgs_trace(scene.native(), camera.native(), params, nat.ptr(compact), stamps.data_ptr(),
                                            None, 1, nat.ptr(b.workspace), b.workspace.numel(), 1, nat.stream()))

@@ -14,15 +14,15 @@ b = HipBackend(scene, camera, 16)
 T = b.tile
 total = ((cfg.width + T - 1) // T) * ((cfg.height + T - 1) // T)
 b.project()
-for split in (False, True):
+for split in (False,):
     out = []
     for world in (16, 8, 4, 2, 1):
         per = (total + world - 1) // world
         compact = b.alloc(per, T, T, 3)
-        for _ in range(5): b.trace(compact, 0, world, compact=True, projected=True, split=split)
+        for _ in range(5): b.trace(compact, 0, world, compact=True, projected=True)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize(); e0.record()
-        for _ in range(50): b.trace(compact, 0, world, compact=True, projected=True, split=split)
+        for _ in range(50): b.trace(compact, 0, world, compact=True, projected=True)
         e1.record(); torch.cuda.synchronize()
         out.append("1/%d: %.1f us" % (world, e0.elapsed_time(e1) / 50 * 1e3))
-    print("   shard trace (%s):" % ("two waves per tile" if split else "one wave per tile"), ", ".join(out))
+    print("   shard trace (%s):" % "one wave per tile", ", ".join(out))

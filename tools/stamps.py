@@ -17,7 +17,7 @@ for world in (1, 8):
     per = (total + world - 1) // world
     compact = b.alloc(per, T, T, 3)
     stamps = torch.zeros((per, 14), dtype=torch.int64, device="cuda")
-    params = nat.RtgsTraceParams(cfg.depth, 0.0, 0, world, nat.TRACE_COMPACT | (nat.TRACE_SPLIT_ON if os.environ.get('RTGS_SPLIT') == '1' else nat.TRACE_SPLIT_OFF))
+    params = nat.RtgsTraceParams(cfg.depth, 0.0, 0, world, nat.TRACE_COMPACT)
     for _ in range(3):
         nat.check(nat.lib().rtgs_trace(scene.native(), camera.native(), params, nat.ptr(compact), stamps.data_ptr(),
                                        None, 1, nat.ptr(b.workspace), b.workspace.numel(), 1, nat.stream()))
