@@ -300,7 +300,9 @@ __global__ __launch_bounds__(kThreads) void k_project(int32_t n, const float* __
     const double k2r = (double)rot[4 * g] * rot[4 * g] + (double)rot[4 * g + 1] * rot[4 * g + 1] +
                        (double)rot[4 * g + 2] * rot[4 * g + 2] + (double)rot[4 * g + 3] * rot[4 * g + 3];
     const double smr = fmax(fabs((double)scale[3 * g]), fmax(fabs((double)scale[3 * g + 1]), fabs((double)scale[3 * g + 2])));
-    const double rr = 1.7320508075688774 * k2r * smr * (1.0 + 1e-9);
+    // (camera-space lengths below are |q_cam|^2 times world lengths -- rc is |q_cam|^2 times a rotation -- so is the radius)
+    const double ksr = sqrt(cam.rc[0] * cam.rc[0] + cam.rc[3] * cam.rc[3] + cam.rc[6] * cam.rc[6]);
+    const double rr = 1.7320508075688774 * k2r * smr * (1.0 + 1e-9) * ksr;
     // camera-space centre: d_cam = rc^T (mu - o), looking along -z
     const double xc = -(cam.rc[0] * mx + cam.rc[3] * my + cam.rc[6] * mz);
     const double yc = -(cam.rc[1] * mx + cam.rc[4] * my + cam.rc[7] * mz);
@@ -506,7 +508,13 @@ __global__ __launch_bounds__(kThreads) void k_project(int32_t n, const float* __
       const double k2 = (double)rot[4 * g] * rot[4 * g] + (double)rot[4 * g + 1] * rot[4 * g + 1] +
                         (double)rot[4 * g + 2] * rot[4 * g + 2] + (double)rot[4 * g + 3] * rot[4 * g + 3];
       const double smax = fmax(fabs((double)scale[3 * g]), fmax(fabs((double)scale[3 * g + 1]), fabs((double)scale[3 * g + 2])));
-      const double lo = sqrt(mx * mx + my * my + mz * mz) - 1.7320508075688774 * k2 * smax;
+      // t1 counts in units of the WORLD direction's length, and the reference's rot_vec3 of a NON-UNIT camera
+      // quaternion stretches that direction by |q_cam|^2 (camera.py:52, utils/quaternion.py:84-96: rc is |q|^2 times
+      // a rotation): a world distance is |q_cam|^2 entry-distance units.  (Round 5: up to here the bound was left in
+      // world units and the horizon test pruned real hits of every ray behind a camera quaternion longer than 1 --
+      // found when the one-entry list, which has no horizon, was retired and its depth-1 test case met this kernel.)
+      const double ks = sqrt(cam.rc[0] * cam.rc[0] + cam.rc[3] * cam.rc[3] + cam.rc[6] * cam.rc[6]);
+      const double lo = (sqrt(mx * mx + my * my + mz * mz) - 1.7320508075688774 * k2 * smax) / ks;
       // (1e-4 relative: the t1 it stands in for is evaluated per ray in fp32 with v_rcp / v_sqrt on
       // fp32-rounded record coefficients, a few 1e-7 relative; the bound must stay below THAT value)
       tmin[g] = lo > 0.0 ? (float)(lo * (1.0 - 1e-4)) : 0.f;   // NaN -> 0: never skipped
@@ -1488,6 +1496,7 @@ __global__ __launch_bounds__(kTraceBlock,
 
 #if RTGS_STAMPS
   t_mark = __builtin_amdgcn_s_memtime();
+  st[3] = t_mark;      // (end of the candidate phase; the two-wave form's list merge used to sit between these two stamps)
 #endif
   // ---- front-to-back compositing of the sorted list (ray_tracer.py:88-104) ----
   // The pixel's coordinates and linear index are formed again from the lane number (laundered, so

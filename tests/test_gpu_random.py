@@ -52,30 +52,38 @@ def test_random_scene_and_camera(seed):
     assert np.abs(att - want["attenuation"])[solid].max() <= U.PIXEL_TOL
 
 
-@pytest.mark.parametrize("seed", [4001, 4003, 4005, 4006])
+@pytest.mark.parametrize("seed", [4001, 4003, 4005, 4006, 4008, 4025, 4026, 4021])   # (4008, 4025, 4026: |q_cam|^2 = 1.43, dense)
 def test_non_unit_quaternions_follow_the_reference_formulas(seed):
     # Gaussian.init does not normalise rotation (gaussian.py:59-84) and quat.as_rotation_mat3 of a
     # non-unit q is |q|^2 times a rotation (utils/quaternion.py:99-121); the same holds for the
     # camera quaternion in rot_vec3 (camera.py:52).  The oracle restates those formulas literally.
+    # Every case at its own random depth AND at depth 16 (round 5: the full-list kernel's horizon test compared a
+    # world-distance bound with entry distances counted in |q_cam|^2 units and dropped real hits behind a camera
+    # quaternion longer than 1 -- seed 4005 only ever ran at its depth 1, through the one-entry list that had no
+    # horizon), and sharded over three image sectors whose projection is culled to them (the same scale in its radius).
+    from test_gpu_render import _weighted_shards_image
     arrays, cam, depth = random_case(seed)
     rng = np.random.default_rng(seed)
     arrays["rotation"] = (arrays["rotation"] * rng.uniform(0.7, 1.4, (arrays["rotation"].shape[0], 1))).astype(np.float32)
     cam["rotation"] = scenes.f32_tuple(np.asarray(cam["rotation"]) * rng.uniform(0.8, 1.25))
-    _, _, tracer = U.build(arrays, cam)
-    tracer.sample_all(depth)
-    torch.cuda.synchronize()
-    want = c_oracle.render(arrays, cam, depth)
-    got = tracer.sample_buf.cpu().numpy().reshape(-1, 3)
-    err = np.abs(got - want["sample"]).max(axis=1)
-    solid = ~want["fragile"]
-    assert np.abs(want["sample"]).max() > 0.05 and solid.mean() >= 0.97
-    assert err[solid].max() <= U.PIXEL_TOL
-    # ray.start / hit distances are in units of the (non-unit) world direction, as in the reference
-    start = tracer.camera.cam_ray_field.start.cpu().numpy().reshape(-1)
-    fin = np.isfinite(want["start"]) & solid
-    assert (np.isfinite(start) == np.isfinite(want["start"]))[solid].all()
-    with np.errstate(invalid="ignore"):
-        assert np.abs(start - want["start"])[fin].max(initial=0.0) <= 2e-5 * max(1.0, np.abs(want["start"][fin]).max(initial=1.0))
+    for d in sorted({depth, 16}):
+        scene, camera, tracer = U.build(arrays, cam)
+        tracer.sample_all(d)
+        torch.cuda.synchronize()
+        want = c_oracle.render(arrays, cam, d)
+        got = tracer.sample_buf.cpu().numpy().reshape(-1, 3)
+        err = np.abs(got - want["sample"]).max(axis=1)
+        solid = ~want["fragile"]
+        assert np.abs(want["sample"]).max() > 0.05 and solid.mean() >= 0.97
+        assert err[solid].max() <= U.PIXEL_TOL, f"seed {seed} depth {d}: {err[solid].max():.3e}, {int(((err > U.PIXEL_TOL) & solid).sum())} pixels"
+        # ray.start / hit distances are in units of the (non-unit) world direction, as in the reference
+        start = tracer.camera.cam_ray_field.start.cpu().numpy().reshape(-1)
+        fin = np.isfinite(want["start"]) & solid
+        assert (np.isfinite(start) == np.isfinite(want["start"]))[solid].all()
+        with np.errstate(invalid="ignore"):
+            assert np.abs(start - want["start"])[fin].max(initial=0.0) <= 2e-5 * max(1.0, np.abs(want["start"][fin]).max(initial=1.0))
+        image, part = _weighted_shards_image(scene, camera, d, ("wedges", 3))
+        assert part.compact and torch.equal(image, tracer.sample_buf), f"seed {seed} depth {d}: sectors with the region cull"
 
 
 def test_non_finite_gaussians_are_culled():
