@@ -951,6 +951,9 @@ __global__ __launch_bounds__(kTraceBlock,
   // staged too and 80 slots = what four workgroups per CU leave: c5 1.304 -> 1.459 ms; its tiles name 66.8 distinct
   // Gaussians on average, 42 % of them more than 80, and a wave with one slot-less lane runs both sources).
   constexpr bool kStage = RTGS_SH_STAGE != 0 && kHasSh && !kBig && !kList;
+  // (round 5, profiles/r05_c3sh_occupancy.txt: 64 slots + a launch bound of five waves per SIMD -- five workgroups per CU
+  // by LDS and by registers -- needs 20 spilled VGPRs in the shading loop: c3 + SH k_trace 0.2397 -> 0.3679 ms;
+  // 64 slots at four waves change nothing)
   constexpr int kStageSlots = 96, kStageStride = 52;
   constexpr unsigned kAbs = 1u << 31;     // kStage payloads: the id field is a Gaussian index (else: a survivor-list slot)
   constexpr int kStageBytes = kStageSlots * kStageStride * (int)sizeof(float);
