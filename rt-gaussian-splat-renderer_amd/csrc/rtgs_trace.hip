@@ -1195,16 +1195,29 @@ __global__ __launch_bounds__(kTraceBlock,
     if (scnt + kSlabStep <= kSlabCap && !last) continue;
     }
     __syncthreads();  // the slab list is complete
-    if (!binned && kSortMax > 0 && scnt > 1 && scnt <= kSortMax) {   // (a bin is sorted already; filtering keeps the order)
+#ifndef RTGS_EXP_COLD
+#define RTGS_EXP_COLD 1
+#endif
+#if RTGS_EXP_COLD == 1
+    if (__builtin_expect(!binned && kSortMax > 0 && scnt > 1 && scnt <= kSortMax, 0)) {   // (a bin is sorted already; filtering keeps the order)
+#else
+    if (!binned && kSortMax > 0 && scnt > 1 && scnt <= kSortMax) {
+#endif
       // nearest slabs first: rank by (key, list position), kSortPer listed slabs per thread (one for
       // lists up to the workgroup size, i.e. practically always: c3 28 slabs per tile on average,
       // 116 at most; c5 58 / 235).  (One wave exchanging the keys by v_readlane instead of LDS, and
       // skipping lists shorter than 8 or 16: all slower, 0.275-0.281 vs 0.270 ms on c3.)
       constexpr int kSortPer = (kSortMax + kBlock - 1) / kBlock;
       int my_slab[kSortPer], rank[kSortPer];
+      // (laundered: the compiler formed (tid, tid + 256) at the top of the kernel, kept the pair through everything
+      // and -- one register short in the main form -- spilled it to scratch for this cold block)
+      int tid_s = tid;
+#if RTGS_EXP_COLD >= 1
+      asm volatile("" : "+v"(tid_s));
+#endif
 #pragma unroll
       for (int q = 0; q < kSortPer; ++q) {
-        const int e = tid + q * kBlock;
+        const int e = tid_s + q * kBlock;
         my_slab[q] = 0; rank[q] = 0;
         if (e < scnt && (q == 0 || scnt > q * kBlock)) {
           my_slab[q] = s_slab[e];
@@ -1218,7 +1231,7 @@ __global__ __launch_bounds__(kTraceBlock,
       __syncthreads();
 #pragma unroll
       for (int q = 0; q < kSortPer; ++q)
-        if (tid + q * kBlock < scnt) s_slab[rank[q]] = (SlabId)my_slab[q];
+        if (tid_s + q * kBlock < scnt) s_slab[rank[q]] = (SlabId)my_slab[q];
       __syncthreads();
     }
 #if RTGS_STAMPS
@@ -1382,12 +1395,17 @@ __global__ __launch_bounds__(kTraceBlock,
             // and A's own polynomial come from the tail, behind a scalar branch
             const bool gen = __float_as_uint(q3.y) != 0u;   // scalar integer compare (the flag is 0.0f or 1.0f)
             float A_gen = 0.f;
+#ifndef RTGS_SALU_EXP
+#define RTGS_SALU_EXP 0
+#endif
+            [[maybe_unused]] float invC_eff = q3.x;         // (wave-uniform: an SGPR)
             if (__builtin_expect(gen, 0)) {
               const float4* tp = tail + (size_t)gi * (kTailFloats / 4);
               const float4 t0 = tp[0], t1v = tp[1];
               if (t1v.w != 0.f) asm volatile("v_swap_b32 %0, %1" : "+v"(x), "+v"(y));
               gx = fmaf(-t1v.z, y, q0.w);
               A_gen = fmaf(y, fmaf(t1v.y, y, t0.z), fmaf(x, fmaf(t1v.x, y, fmaf(t0.w, x, t0.y)), t0.x));
+              invC_eff = 0.f;
             }
             const float u = fmaf(q1.z, y, x);
             float e = fmaf(x, gx, q0.z);
@@ -1431,7 +1449,13 @@ __global__ __launch_bounds__(kTraceBlock,
               t_front += ti0 - t_loop0;
 #endif
               // A = d^T Sigma^-1 d from delta/4 = b^2 - A C (compact records), or its own polynomial
+#if RTGS_SALU_EXP
+              // no select on the class: (b^2 - delta/4) * (1/C) + 0 for the compact records (the product, rounded once:
+              // the same bits as the multiplication), 0 * (...) + A's own polynomial for class 1
+              const float A = fmaf(fmaf(bq, bq, -e), invC_eff, A_gen);
+#else
               const float A = gen ? A_gen : fmaf(bq, bq, -e) * q3.x;
+#endif
               const float wn = e * __builtin_amdgcn_rcpf(A);
 #if RTGS_ABLATE == 1
               asm volatile("" ::"v"(kn), "v"(wn));
