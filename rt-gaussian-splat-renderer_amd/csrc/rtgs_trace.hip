@@ -590,6 +590,9 @@ __host__ __device__ inline int bin_stride_of(size_t nslabs) {
   return (int)((c + 3) & ~(size_t)3);
 }
 
+// which macro-tiles a projection's bins are for (all of them: step <= 1 and no rectangle)
+struct BinOwner { int32_t first, step; int32_t rect_on; float4 rect; };
+
 template <bool kGroups>   // kGroups: bounds of kSuper-slab groups first (scenes with k_super_bbox's output)
 __global__ __launch_bounds__(256) void k_bin(int32_t nslabs, const float4* __restrict__ slab_bbox,
                                               const float4* __restrict__ super_bbox,
@@ -597,7 +600,7 @@ __global__ __launch_bounds__(256) void k_bin(int32_t nslabs, const float4* __res
                                               int32_t shift, int32_t bin_sx, int32_t stride,
                                               int32_t* __restrict__ bin_count, int32_t* __restrict__ bin_list,
                                               int32_t* __restrict__ tile_bin, int32_t tiles_x, int32_t tiles_y,
-                                              const size_t frame_stride) {
+                                              const size_t frame_stride, const BinOwner own) {
   if (frame_stride) {      // frames batched into one launch: blockIdx.y = frame (see k_project)
     const size_t fo = (size_t)blockIdx.y * frame_stride;
     slab_bbox = at_frame(slab_bbox, fo); super_bbox = at_frame(super_bbox, fo); slab_key = at_frame(slab_key, fo);
@@ -619,6 +622,29 @@ __global__ __launch_bounds__(256) void k_bin(int32_t nslabs, const float4* __res
   // bounds of the pixel centres the supertile covers (the macro-tiles' own bounds lie inside)
   const float Xlo = ((float)i0 + 0.5f) - hw, Xhi = ((float)min(i0 + edge, width) - 0.5f) - hw;
   const float Ylo = ((float)j0 + 0.5f) - hh, Yhi = ((float)min(j0 + edge, height) - 0.5f) - hh;
+  // A shard's own projection (rtgs_shard_frame(s): this frame's bins are read by THAT shard's trace and nobody else)
+  // only needs the bins of the tiles the shard owns: macro-tile t with (t - first) mod step == 0, inside the shard's
+  // region rectangle when it has one.  A supertile without an owned tile is skipped whole -- every second one of a
+  // round-robin 1/8 shard, three quarters of the frame for one image sector in eight -- and so are the other tiles'
+  // lists (k_bin was 13 % of a rank's 1080p frame at 8 ranks, 10 % of a 4K one).
+  auto owned = [&](int tx, int ty) -> bool {
+    if (tx >= tiles_x || ty >= tiles_y) return false;
+    if (own.step > 1 && (ty * tiles_x + tx - own.first) % own.step != 0) return false;
+    if (own.rect_on) {
+      const float xl = ((float)(tx * kTile) + 0.5f) - hw, xh = ((float)min(tx * kTile + kTile, width) - 0.5f) - hw;
+      const float yl = ((float)(ty * kTile) + 0.5f) - hh, yh = ((float)min(ty * kTile + kTile, height) - 0.5f) - hh;
+      if (xl > own.rect.z || xh < own.rect.x || yl > own.rect.w || yh < own.rect.y) return false;
+    }
+    return true;
+  };
+  const bool restricted = own.step > 1 || own.rect_on != 0;
+  if (restricted) {
+    const int per_edge_o = 1 << shift;
+    bool mine = false;
+    for (int t = tid; t < per_edge_o * per_edge_o; t += 256)
+      mine = mine || owned((st % bin_sx) * per_edge_o + (t % per_edge_o), (st / bin_sx) * per_edge_o + (t / per_edge_o));
+    if (!__syncthreads_or(mine ? 1 : 0)) return;     // (uniform: nobody owns a tile here)
+  }
   int cnt = 0, par = 0;
   bool over = false;
   int nitems = nslabs;
@@ -740,7 +766,7 @@ __global__ __launch_bounds__(256) void k_bin(int32_t nslabs, const float4* __res
       for (int q = 0; q < 4; ++q) {
         const int t = t0 + q;
         const int tx = (st % bin_sx) * per_edge + (t % per_edge), ty = (st / bin_sx) * per_edge + (t / per_edge);
-        const bool in = t < ntl && tx < tiles_x && ty < tiles_y;
+        const bool in = t < ntl && tx < tiles_x && ty < tiles_y && (!restricted || owned(tx, ty));
         const int mi0 = tx * kTile, mj0 = ty * kTile;
         // (a tile outside the frame gets bounds nothing overlaps and no output)
         tXlo[q] = in ? ((float)mi0 + 0.5f) - hw : kInf;
@@ -1195,14 +1221,8 @@ __global__ __launch_bounds__(kTraceBlock,
     if (scnt + kSlabStep <= kSlabCap && !last) continue;
     }
     __syncthreads();  // the slab list is complete
-#ifndef RTGS_EXP_COLD
-#define RTGS_EXP_COLD 1
-#endif
-#if RTGS_EXP_COLD == 1
-    if (__builtin_expect(!binned && kSortMax > 0 && scnt > 1 && scnt <= kSortMax, 0)) {   // (a bin is sorted already; filtering keeps the order)
-#else
-    if (!binned && kSortMax > 0 && scnt > 1 && scnt <= kSortMax) {
-#endif
+    // (a bin is sorted already; filtering keeps the order.  Marked unlikely: c3 0.1286 -> 0.1278 ms, c5 1.295 -> 1.2885)
+    if (__builtin_expect(!binned && kSortMax > 0 && scnt > 1 && scnt <= kSortMax, 0)) {
       // nearest slabs first: rank by (key, list position), kSortPer listed slabs per thread (one for
       // lists up to the workgroup size, i.e. practically always: c3 28 slabs per tile on average,
       // 116 at most; c5 58 / 235).  (One wave exchanging the keys by v_readlane instead of LDS, and
@@ -1212,9 +1232,7 @@ __global__ __launch_bounds__(kTraceBlock,
       // (laundered: the compiler formed (tid, tid + 256) at the top of the kernel, kept the pair through everything
       // and -- one register short in the main form -- spilled it to scratch for this cold block)
       int tid_s = tid;
-#if RTGS_EXP_COLD >= 1
       asm volatile("" : "+v"(tid_s));
-#endif
 #pragma unroll
       for (int q = 0; q < kSortPer; ++q) {
         const int e = tid_s + q * kBlock;
@@ -1395,10 +1413,7 @@ __global__ __launch_bounds__(kTraceBlock,
             // and A's own polynomial come from the tail, behind a scalar branch
             const bool gen = __float_as_uint(q3.y) != 0u;   // scalar integer compare (the flag is 0.0f or 1.0f)
             float A_gen = 0.f;
-#ifndef RTGS_SALU_EXP
-#define RTGS_SALU_EXP 0
-#endif
-            [[maybe_unused]] float invC_eff = q3.x;         // (wave-uniform: an SGPR)
+            float invC_eff = q3.x;                          // (wave-uniform: an SGPR)
             if (__builtin_expect(gen, 0)) {
               const float4* tp = tail + (size_t)gi * (kTailFloats / 4);
               const float4 t0 = tp[0], t1v = tp[1];
@@ -1449,13 +1464,11 @@ __global__ __launch_bounds__(kTraceBlock,
               t_front += ti0 - t_loop0;
 #endif
               // A = d^T Sigma^-1 d from delta/4 = b^2 - A C (compact records), or its own polynomial
-#if RTGS_SALU_EXP
-              // no select on the class: (b^2 - delta/4) * (1/C) + 0 for the compact records (the product, rounded once:
-              // the same bits as the multiplication), 0 * (...) + A's own polynomial for class 1
+              // no select on the class (round 5: it kept the class test as a 64-bit mask -- compare, cselect, and, branch
+              // per candidate; now compare + branch, c3 0.1288 -> 0.1273 ms): (b^2 - delta/4) * (1/C) + 0 for the compact
+              // records (the product, rounded once: the same bits as the multiplication), 0 * (...) + A's own polynomial
+              // for class 1
               const float A = fmaf(fmaf(bq, bq, -e), invC_eff, A_gen);
-#else
-              const float A = gen ? A_gen : fmaf(bq, bq, -e) * q3.x;
-#endif
               const float wn = e * __builtin_amdgcn_rcpf(A);
 #if RTGS_ABLATE == 1
               asm volatile("" ::"v"(kn), "v"(wn));
@@ -2246,8 +2259,13 @@ static int32_t* tile_bin_of(int32_t* bin_count, size_t nslabs, int width, int he
 // which the kernels read instead of `cam`'s pose
 static int project_impl(const RtgsScene* scene, const RtgsCamera* cam, void* workspace,
                         size_t workspace_bytes, rtgs_stream_t stream, bool want_bins, const float* region = nullptr,
-                        int32_t frames = 1, size_t frame_stride = 0, const FrameCam* pose0 = nullptr) {
+                        int32_t frames = 1, size_t frame_stride = 0, const FrameCam* pose0 = nullptr,
+                        int32_t own_first = 0, int32_t own_step = 1, bool own_region = false) {
   if (int rc = validate(scene, cam, workspace, workspace_bytes)) return rc;
+  BinOwner own;
+  own.first = own_first; own.step = own_step;
+  own.rect_on = (own_region && region) ? 1 : 0;
+  own.rect = region ? make_float4(region[0], region[1], region[2], region[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
   const FrameCam* const pose = frames > 1 ? pose0 : static_cast<const FrameCam*>(cam->device_pose);
   const size_t fstride = frames > 1 ? frame_stride : 0;
   const size_t nn = ((size_t)scene->n + 63) & ~(size_t)63;
@@ -2283,11 +2301,11 @@ static int project_impl(const RtgsScene* scene, const RtgsCamera* cam, void* wor
     if (groups)
       hipLaunchKernelGGL(k_bin<true>, dim3(g.supertiles, frames), dim3(256), 0, static_cast<hipStream_t>(stream), nslabs,
                          slab_bbox, slab_bbox + nslabs, keys, cam->width, cam->height, g.shift, g.sx,
-                         bin_stride_of(nslabs), bin_count, bin_count + kBinSupertilesMax, tile_bin, tiles_x, tiles_y, fstride);
+                         bin_stride_of(nslabs), bin_count, bin_count + kBinSupertilesMax, tile_bin, tiles_x, tiles_y, fstride, own);
     else
       hipLaunchKernelGGL(k_bin<false>, dim3(g.supertiles, frames), dim3(256), 0, static_cast<hipStream_t>(stream), nslabs,
                          slab_bbox, slab_bbox + nslabs, keys, cam->width, cam->height, g.shift, g.sx,
-                         bin_stride_of(nslabs), bin_count, bin_count + kBinSupertilesMax, tile_bin, tiles_x, tiles_y, fstride);
+                         bin_stride_of(nslabs), bin_count, bin_count + kBinSupertilesMax, tile_bin, tiles_x, tiles_y, fstride, own);
   }
   return check_launch();
 }
@@ -2330,7 +2348,8 @@ static int trace_impl(const RtgsScene* scene, const RtgsCamera* cam, const RtgsT
                       float* sample_buf, float* attenuation_buf, float* ray_start,
                       int32_t ray_start_stride, void* workspace, size_t workspace_bytes,
                       int32_t projected, int32_t tile_limit, rtgs_stream_t stream, void* lists = nullptr,
-                      int32_t frames = 1, size_t frame_stride = 0, size_t out_stride = 0, const FrameCam* pose0 = nullptr) {
+                      int32_t frames = 1, size_t frame_stride = 0, size_t out_stride = 0, const FrameCam* pose0 = nullptr,
+                      bool own_bins = false) {
   if (!params || (!sample_buf && !lists)) return RTGS_EINVAL;
   if (frames > 1 && (lists || attenuation_buf || ray_start || params->depth > RTGS_MAX_DEPTH)) return RTGS_EINVAL;
   if (int rc = validate(scene, cam, workspace, workspace_bytes)) return rc;
@@ -2348,7 +2367,8 @@ static int trace_impl(const RtgsScene* scene, const RtgsCamera* cam, const RtgsT
       p.depth = left > RTGS_MAX_DEPTH ? RTGS_MAX_DEPTH : left;
       if (link > 0) p.flags |= RTGS_TRACE_RESUME | RTGS_TRACE_ACCUMULATE;
       if (int rc = trace_impl(scene, cam, &p, sample_buf, attenuation_buf, ray_start, ray_start_stride,
-                              workspace, workspace_bytes, link > 0 ? 1 : projected, tile_limit, stream, nullptr))
+                              workspace, workspace_bytes, link > 0 ? 1 : projected, tile_limit, stream, nullptr, 1, 0, 0,
+                              nullptr, own_bins))
         return rc;
       left -= p.depth;
     }
@@ -2374,8 +2394,13 @@ static int trace_impl(const RtgsScene* scene, const RtgsCamera* cam, const RtgsT
     bool want_bins = shard_wants_bins(cam, (int32_t)std::min<int64_t>((int64_t)local * frames, INT32_MAX));
     if (params->flags & RTGS_TRACE_BINS_ON) want_bins = true;
     if (params->flags & RTGS_TRACE_BINS_OFF) want_bins = false;
+    // own_bins (rtgs_shard_frame(s): projection and trace of ONE shard, paired per frame): the bins of the shard's
+    // own tiles only.  rtgs_trace keeps whole-frame bins -- a caller may trace other shards from this projection
+    const bool listed_ = (params->flags & RTGS_TRACE_TILE_LIST) != 0;
     if (int rc = project_impl(scene, cam, workspace, workspace_bytes, stream, want_bins,
-                              (params->flags & RTGS_TRACE_REGION) ? params->region : nullptr, frames, frame_stride, pose0))
+                              (params->flags & RTGS_TRACE_REGION) ? params->region : nullptr, frames, frame_stride, pose0,
+                              (own_bins && !listed_) ? params->tile_first : 0, (own_bins && !listed_) ? params->tile_step : 1,
+                              own_bins && listed_ && (params->flags & RTGS_TRACE_REGION)))
       return rc;
   }
 
@@ -2579,7 +2604,7 @@ int rtgs_shard_frame(const RtgsScene* scene, const RtgsCamera* cam, const RtgsTr
     if (hipStreamWaitEvent(rs, static_cast<hipEvent_t>(reuse_event), 0) != hipSuccess) return RTGS_EDEVICE;
   }
   if (int rc = trace_impl(scene, cam, params, out, attenuation_buf, ray_start, 1, workspace, workspace_bytes, 0,
-                          INT32_MAX, render_stream))
+                          INT32_MAX, render_stream, nullptr, 1, 0, 0, nullptr, true))
     return rc;
   if (hipEventRecord(static_cast<hipEvent_t>(traced_event), rs) != hipSuccess) return RTGS_EDEVICE;
   if (consumer_waits &&
@@ -2659,12 +2684,12 @@ int rtgs_shard_frames(const RtgsScene* scene, const RtgsCamera* cams, int32_t n_
                          ws + pose_off, region, g);
       if (int rc = trace_impl(scene, &cams[k], params, outs[k], nullptr, nullptr, 1, ws, region, 0, INT32_MAX,
                               render_streams[si], nullptr, g, region, (size_t)step,
-                              reinterpret_cast<const FrameCam*>(ws + pose_off)))
+                              reinterpret_cast<const FrameCam*>(ws + pose_off), true))
         return rc;
     } else {
       if (int rc = trace_impl(scene, &cams[k], params, outs[k], attenuation_bufs ? attenuation_bufs[si] : nullptr,
                               ray_starts ? ray_starts[si] : nullptr, 1, workspaces[si], workspace_bytes, 0, INT32_MAX,
-                              render_streams[si]))
+                              render_streams[si], nullptr, 1, 0, 0, nullptr, true))
         return rc;
     }
     k += g;
