@@ -65,6 +65,8 @@ def parse(argv=None):
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="c3", help="c2 | c3 | c5 (SURVEY.md 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--min-timed-s", type=float, default=MIN_TIMED_S, help="the K-step batch is repeated until this much has "
+                    "been timed (profiling runs under rocprofv3 --pmc, where every launch is serialised, pass less)")
     ap.add_argument("--no-scene-hit", action="store_true", help="skip the arbitrary-ray Scene.hit figure")
     ap.add_argument("--no-secondary", action="store_true", help="headline only: no Scene.hit and no t_cutoff "
                     "figures (profiling runs: their kernels would be averaged into k_trace's counters)")
@@ -463,7 +465,7 @@ def rank_main(args) -> int:
         # The same K-step batch is repeated until MIN_TIMED_S has been timed (the decision uses the
         # all-reduced time: identical on every rank) and the MEDIAN batch is the one reported.
         batches = [timed_batch()]
-        while sum(batches) < MIN_TIMED_S and len(batches) < MAX_BATCHES:
+        while sum(batches) < args.min_timed_s and len(batches) < MAX_BATCHES:
             batches.append(timed_batch())
         elapsed = sorted(batches)[len(batches) // 2]
 

@@ -2053,6 +2053,8 @@ __global__ __launch_bounds__(256) void k_untile_map(RankBufs bufs, const int32_t
   if (p >= width * height) return;
   const int i = p / height, j = p % height;
   const int m = tile_map[(j / kTile) * tiles_x + i / kTile];
+  // (a malformed caller-supplied map -- a rank beyond the buffers passed, or one without a buffer -- must not be followed)
+  if ((unsigned)m >> 24 >= (unsigned)kMaxRanks || !bufs.p[m >> 24]) return;
   const float* s = bufs.p[m >> 24] + ((size_t)(m & 0xFFFFFF) * kTile * kTile + (size_t)(i % kTile) * kTile + (j % kTile)) * 3;
   float* o = image + (size_t)p * 3;
   o[0] = s[0]; o[1] = s[1]; o[2] = s[2];
