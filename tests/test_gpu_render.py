@@ -1304,6 +1304,43 @@ def test_rotating_roots_land_their_frames_bit_exact_without_host_syncs(rank, in_
     r0.close()
 
 
+@pytest.mark.parametrize("name", ["sh", "mid_sh", "large", "large_sh"])
+def test_frames_batched_into_one_launch_equal_frames_launched_one_by_one(name, monkeypatch):
+    # round 5: rtgs_shard_frames renders runs of consecutive frames with ONE k_project / k_bin / k_trace each (grid.y =
+    # frames, the kMulti forms, pose blocks in the workspace, bins restricted to the shard's tiles) when the stream's
+    # workspace has room.  Every form -- SH staged in LDS (sh, mid_sh: with bins), the two-level scan (large), both
+    # (large_sh) -- must write, for six frames of six poses, exactly the bytes the same call writes frame by frame.
+    from rtgs.parallel import TileParallelRenderer, _no_all_to_all
+    if name == "sh":
+        arrays, cam, depth = U.case("sh")
+    else:
+        n = 40_000 if name == "mid_sh" else 270_000
+        w, h = 192, 108
+        arrays, cam, depth = synthetic.make_scene(n, w / h, 77, sh=name.endswith("sh")), synthetic.bench_camera(w, h), 16
+    scene, camera, _ = U.build(arrays, cam)
+    p0 = np.asarray(cam["position"], np.float64)
+    rng = np.random.default_rng(3)
+    poses = [(tuple(p0 + d), tuple(cam["rotation"])) for d in rng.uniform(-0.2, 0.2, (6, 3))]
+    outs = {}
+    for merge in ("1", "8"):
+        monkeypatch.setenv("RTGS_MERGE_FRAMES", merge)
+        for deal in ("equal", "wedges"):
+            r = TileParallelRenderer(scene, camera, depth=depth, rank=1, world=2, landing="rotate", gather_batch=6,
+                                     a2a_fn=_no_all_to_all, partition=deal)
+            assert r.frames_per_launch == (1 if merge == "1" else 6)
+            for buf in r.compact:
+                buf.fill_(-5.0)
+            r.render_frames(poses)
+            r.finish()
+            torch.cuda.synchronize()
+            outs[(merge, deal)] = r.compact[0].clone()
+            r.close()
+    for deal in ("equal", "wedges"):
+        a, b = outs[("1", deal)], outs[("8", deal)]
+        assert float(a.abs().sum()) > 0 and not torch.equal(a[0], a[1])          # six different frames
+        assert torch.equal(a, b), f"{name} {deal}: batched frames differ from frames launched one by one"
+
+
 @pytest.mark.parametrize("shares", [(63, 1), (1, 0), (3, 1, 2)])
 def test_non_destination_rank_loop_with_small_and_empty_shares(shares):
     # round 4: the two-rank rehearsal of the calibrated deal gave rank 1 NO tiles (64/0); a NULL tile list then meant
