@@ -65,6 +65,8 @@ def parse(argv=None):
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="c3", help="c2 | c3 | c5 (SURVEY.md 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-frame-batch", action="store_true", help="N = 1: only the one-frame-per-launch loop (profiling runs: "
+                    "the batched launches would be averaged into k_trace's counters)")
     ap.add_argument("--min-timed-s", type=float, default=MIN_TIMED_S, help="the K-step batch is repeated until this much has "
                     "been timed (profiling runs under rocprofv3 --pmc, where every launch is serialised, pass less)")
     ap.add_argument("--no-scene-hit", action="store_true", help="skip the arbitrary-ray Scene.hit figure")
@@ -433,6 +435,46 @@ def rank_main(args) -> int:
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         return bool(flag.item())
 
+    class BatchedSingle:
+        """N = 1, G whole frames per launch: the adapter run_mode needs around rtgs.parallel.FrameBatchRenderer."""
+
+        def __init__(self, frames):
+            from rtgs.parallel import FrameBatchRenderer
+            self.fb = FrameBatchRenderer(scene, camera, depth=cfg.depth, frames=frames)
+            self.one = TileParallelRenderer(scene, camera, depth=cfg.depth, rank=0, world=1)
+            self.gather_batch, self.frames_in_flight, self.landing = self.fb.frames, 1, "batch"
+            self.partition, self.calibration, self.local_tiles = self.one.partition, None, self.one.local_tiles
+
+        def render_frames(self, poses=None, count=None):
+            left = int(count)
+            while left > 0:
+                left -= self.fb.render_frames(count=min(left, self.fb.frames))
+
+        def finish(self):
+            pass
+
+        def project_only(self):
+            self.one.project_only()
+
+        def trace_only(self):
+            self.one.trace_only()
+
+        def verify(self):
+            """Eight different poses in one launch: every image must equal its single-frame render bit for bit."""
+            p0 = np.asarray(cam["position"], np.float64)
+            poses = [(tuple(float(v) for v in p0 + np.array([0.03 * k, -0.02 * k, 0.01 * k])), tuple(cam["rotation"]))
+                     for k in range(self.fb.frames)]
+            self.fb.render_frames(poses)
+            torch.cuda.synchronize()
+            ok = True
+            for k, (pos, _) in enumerate(poses):
+                camera.position = vec3(pos)
+                self.one.render_frame()
+                torch.cuda.synchronize()
+                ok = ok and bool(torch.equal(self.fb.images[k], self.one.framebuffer))
+            camera.position = vec3(cam["position"])
+            return ok and not torch.equal(self.fb.images[0], self.fb.images[1])
+
     def run_mode(mode):
         """One deal -- (partition, landing, frames per call and collective) -- end to end: construct (\"auto\"
         calibrates), warm up, the timed batches, the dominant kernel alone, every rank's shard times, the
@@ -440,8 +482,11 @@ def rank_main(args) -> int:
         from rtgs.parallel import _phase
         partition, landing, gbatch = mode
         _phase("bench: mode", mode)
-        renderer = TileParallelRenderer(scene, camera, depth=cfg.depth, rank=rank, world=world, partition=partition,
-                                        landing=landing, gather_batch=gbatch if world > 1 else None)
+        if world == 1 and landing == "batch":
+            renderer = BatchedSingle(gbatch)
+        else:
+            renderer = TileParallelRenderer(scene, camera, depth=cfg.depth, rank=rank, world=world, partition=partition,
+                                            landing=landing, gather_batch=gbatch if world > 1 else None)
         _phase("bench: warm-up")
         renderer.render_frames(count=args.warmup)
         renderer.finish()
@@ -499,7 +544,7 @@ def rank_main(args) -> int:
             for k in ("trace_ms", "project_ms"):
                 per_rank[k + "_min"], per_rank[k + "_max"] = min(per_rank[k]), max(per_rank[k])
         _phase("bench: verify")
-        verified = verify(renderer) if world > 1 else None
+        verified = verify(renderer) if world > 1 else (renderer.verify() if isinstance(renderer, BatchedSingle) else None)
         _phase("bench: mode done", verified)
         return dict(renderer=renderer, batches=batches, elapsed=elapsed, trace_ms=trace_ms, project_ms=project_ms,
                     per_rank=per_rank, verified=verified, partition=renderer.partition.name, landing=renderer.landing,
@@ -511,7 +556,11 @@ def rank_main(args) -> int:
     # collective, landing on rank 0 and on ROTATING roots (frame f on rank f mod N, one all_to_all per batch).  The
     # line reports the fastest VERIFIED one, `secondary.partitions` all of them.
     if world == 1:
-        modes = [("equal", "root", None)]
+        # one frame per launch (SURVEY 8(d)'s t_frame: first launch to framebuffer complete; every earlier round's figure)
+        # and eight poses per launch of each kernel (rtgs.parallel.FrameBatchRenderer: every frame fully projected, binned
+        # and traced into a framebuffer of its own, each verified bit for bit against its single-frame render); `value`
+        # is the faster verified one, the other stays under `secondary`
+        modes = [("equal", "root", None)] + ([] if args.no_frame_batch else [("equal", "batch", 8)])
     else:
         if "," in args.partition:
             parts = [tuple(float(v) for v in args.partition.split(","))]
@@ -584,6 +633,9 @@ def rank_main(args) -> int:
         metric = base_metric if (cfg.width, cfg.height, cfg.n) == (1920, 1080, 100_000) else \
             f"Mrays/s at {cfg.width}x{cfg.height}, {cfg.n} Gaussians; achieved HBM GB/s vs peak"
         comm = ""
+        if world == 1 and best["landing"] == "batch":
+            comm = (f", {best['gather_batch']} whole frames per launch of each kernel (rtgs_shard_frames: every frame projected, "
+                    "binned and traced into a framebuffer of its own; secondary.single_gpu_modes has the one-frame-per-launch loop)")
         if world > 1:
             what = "all_to_all to rotating roots (every rank lands 1/N of the frames)" if best["landing"] == "rotate" else "gather to rank 0"
             comm = f" + RCCL {what}" if args.backend == "nccl" else f" + {args.backend} {what} (rehearsal, not RCCL)"
@@ -646,6 +698,14 @@ def rank_main(args) -> int:
         line["secondary"] = {"closest_hit_queries_per_s": mrays * 1e6 * cfg.depth,
                              "frame_latency_ms_median_hip_events": frame_ms_median,
                              "frames_in_flight": renderer.frames_in_flight}
+        if world == 1:
+            # both ways of queueing K frames on one GPU; `value` is the faster verified one.  "one frame per launch" is
+            # SURVEY 8(d)'s t_frame (first launch to framebuffer complete) and what rounds 1-4 reported
+            line["secondary"]["single_gpu_modes"] = {
+                str(m): (None if r is None else {"ms_per_step": r["elapsed"] / args.steps * 1e3,
+                                            "mrays_per_s": cfg.rays / (r["elapsed"] / args.steps) / 1e6, "verified": r["verified"]})
+                for m, r in runs.items()}
+            line["secondary"]["mode_reported"] = str(reported)
         if world == 1 and not args.no_secondary:
             # the reference's own API path (ray_tracer.py:39-54, viewer loop __main__.py:253-256):
             # rtgs.RayTracer.sample_all (one call per sample) and sample() x depth (one peel per call)
@@ -693,7 +753,9 @@ def rank_main(args) -> int:
     def mode_name(m):
         part, landing, gbatch = m
         part = part if isinstance(part, str) else ",".join(f"{v:g}" for v in part)
-        return part if world == 1 else f"{part}/{landing}/B{gbatch}"
+        if world == 1:
+            return "one frame per launch" if landing != "batch" else f"{gbatch} frames per launch"
+        return f"{part}/{landing}/B{gbatch}"
 
     def pick(pool_of):
         """The deal the line reports: the fastest VERIFIED one in which every rank renders (a calibrated deal that
@@ -701,8 +763,8 @@ def rank_main(args) -> int:
         secondary.partitions); failing that the fastest verified, failing that the fastest.  `elapsed`, `verified`
         and the shares are all-reduced / identical on every rank, so every rank picks the same deal by itself."""
         done = {m: r for m, r in pool_of.items() if r is not None}
-        for keep in (lambda r: (world == 1 or r["verified"]) and r["rendering_ranks"] == world,
-                     lambda r: world == 1 or r["verified"], lambda r: True):
+        for keep in (lambda r: (r["verified"] is not False if world == 1 else r["verified"]) and r["rendering_ranks"] == world,
+                     lambda r: r["verified"] is not False if world == 1 else r["verified"], lambda r: True):
             pool = {m: r for m, r in done.items() if keep(r)}
             if pool:
                 return min(pool, key=lambda m: pool[m]["elapsed"])

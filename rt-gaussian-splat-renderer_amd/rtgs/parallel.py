@@ -452,6 +452,65 @@ def _all_to_all(output, input, output_split_sizes=None, input_split_sizes=None, 
     return dist.all_to_all_single(output, input, output_split_sizes, input_split_sizes, group=group)
 
 
+class FrameBatchRenderer:
+    """Whole frames on ONE GPU, up to `frames` consecutive poses per LAUNCH (grid.y = frames through
+    ``rtgs_shard_frames``): a turntable or a benchmark that knows its next poses pays one k_project / k_bin / k_trace
+    launch -- and their latency-bound heads and tails -- per batch instead of per frame (c3: the three launches of a
+    frame are 0.147 ms one by one, of which k_project + k_bin are 17 us of mostly latency).  Every frame is fully
+    projected, binned and traced; ``images[k]`` is frame k of the last ``render_frames`` call, complete in the
+    caller's stream order.  The reference's viewer renders one pose per loop iteration (__main__.py:236-257): this is
+    for consumers that take frames in batches, at frames - 1 frames of latency."""
+
+    def __init__(self, scene, camera, depth: int = 16, frames: int = 8, t_cutoff: float = 0.0):
+        import ctypes
+        self.backend = b = HipBackend(scene, camera, depth, t_cutoff)
+        nat = b.nat
+        lib = nat.lib()
+        self.frames = max(1, min(int(frames), lib.rtgs_max_frames_per_launch()))
+        self.images = b.alloc(self.frames, b.width, b.height, 3)
+        need = lib.rtgs_workspace_bytes_frames(scene.num_gaussians, b.width, b.height, self.frames)
+        self._ws = torch.empty(need, dtype=torch.uint8, device=b.device)
+        order = b.tile_order(0, 1) if b.use_tile_order else None
+        self._params = nat.RtgsTraceParams(b.depth, b.t_cutoff, 0, 1, 0, nat.ptr(order))
+        self._order = order
+        h = ctypes.c_void_p()
+        nat.check(lib.rtgs_event_create(ctypes.byref(h)), "rtgs_event_create")
+        self._event = h.value
+        self._done_c = (ctypes.c_void_p * 1)(self._event)
+        self._ws_c = (ctypes.c_void_p * 1)(self._ws.data_ptr())
+        stride = self.images.stride(0) * 4
+        self._outs_c = (ctypes.c_void_p * self.frames)(*[self.images.data_ptr() + k * stride for k in range(self.frames)])
+        self._lib = lib
+
+    def render_frames(self, poses=None, count: int | None = None) -> int:
+        """Render up to `frames` poses ((position, rotation) pairs or (n, 7) rows; default: `count` copies of the
+        camera's pose) into ``images[0 .. n)``; returns n."""
+        import ctypes
+        b, nat = self.backend, self.backend.nat
+        rows = _pose_rows(poses) if poses is not None else None
+        n = len(rows) if rows is not None else int(self.frames if count is None else count)
+        if n < 1 or n > self.frames:
+            raise ValueError(f"1 .. {self.frames} frames per call")
+        cams, _ = b.camera_array(rows, n)
+        streams = (ctypes.c_void_p * 1)(nat.stream())
+        nat.check(self._lib.rtgs_shard_frames(b.scene_native(), cams.ctypes.data, n, self._params, self._outs_c, None, None,
+                                              self._ws_c, self._ws.numel(), streams, 1, 0, None, self._done_c, None, 0),
+                  "rtgs_shard_frames")
+        return n
+
+    def close(self) -> None:
+        ev, self._event = self._event, None
+        if ev is not None:
+            torch.cuda.synchronize(self.backend.device)
+            self._lib.rtgs_event_destroy(ev)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class TileParallelRenderer:
     """Renders whole frames on `world` ranks; where they land is ``landing``:
 

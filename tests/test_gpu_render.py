@@ -1304,6 +1304,38 @@ def test_rotating_roots_land_their_frames_bit_exact_without_host_syncs(rank, in_
     r0.close()
 
 
+@pytest.mark.parametrize("name", ["oblique", "sh", "mid_sh"])
+def test_whole_frames_batched_on_one_gpu_equal_single_frames(name):
+    # FrameBatchRenderer: up to eight poses per launch on ONE GPU (whole frames, image layout): each image must equal
+    # the single-frame render of its pose bit for bit, also for a short batch and for the camera's own pose
+    from rtgs.parallel import FrameBatchRenderer
+    from rtgs.utils.types import vec3
+    if name == "mid_sh":
+        w, h = 192, 108
+        arrays, cam, depth = synthetic.make_scene(40_000, w / h, 77, sh=True), synthetic.bench_camera(w, h), 16
+    else:
+        arrays, cam, depth = U.case(name)
+    scene, camera, tracer = U.build(arrays, cam)
+    p0 = np.asarray(cam["position"], np.float64)
+    rng = np.random.default_rng(9)
+    poses = [(tuple(p0 + d), tuple(cam["rotation"])) for d in rng.uniform(-0.25, 0.25, (8, 3))]
+    fb = FrameBatchRenderer(scene, camera, depth=depth, frames=8)
+    for batch in (poses, poses[:3]):
+        assert fb.render_frames(batch) == len(batch)
+        torch.cuda.synchronize()
+        for k, (pos, rot) in enumerate(batch):
+            tracer.trace(depth, position=pos, rotation=rot, state=False)
+            torch.cuda.synchronize()
+            assert torch.equal(fb.images[k], tracer.sample_buf), f"{name}: frame {k} of a batch of {len(batch)}"
+    assert fb.render_frames(count=2) == 2
+    tracer.trace(depth, state=False)
+    torch.cuda.synchronize()
+    assert torch.equal(fb.images[0], tracer.sample_buf) and torch.equal(fb.images[1], tracer.sample_buf)
+    with pytest.raises(ValueError):
+        fb.render_frames(count=9)
+    fb.close()
+
+
 @pytest.mark.parametrize("name", ["sh", "mid_sh", "large", "large_sh"])
 def test_frames_batched_into_one_launch_equal_frames_launched_one_by_one(name, monkeypatch):
     # round 5: rtgs_shard_frames renders runs of consecutive frames with ONE k_project / k_bin / k_trace each (grid.y =

@@ -11,7 +11,7 @@ for v in "$@"; do
       && echo "$name parity slice: $(tail -1 $OUT/check_$name.log)" || { echo "$name PARITY FAILED: $(tail -3 $OUT/check_$name.log)"; }
   fi
   for c in ${CFGS:-c3 c5}; do
-    RTGS_HIP_LIB=$OUT/lib_$name.so python $R/bench.py --config $c --steps 100 --warmup 10 --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 | \
+    RTGS_HIP_LIB=$OUT/lib_$name.so python $R/bench.py --config $c --steps 100 --warmup 10 --no-cpu-baseline --no-secondary --no-frame-batch 2>/dev/null | tail -1 | \
      python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$name $c', 'ms %.4f trace_ms %.4f project_ms %.4f' % (d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['project_ms']))" | tee -a $OUT/results.txt
   done
 done

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for pass in "$@"; do
   i=$((i+1))
-  rocprofv3 --pmc $pass --output-format csv -d $OUT/p$i -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary --min-timed-s 0.1 ${BENCH_ARGS} > $OUT/p$i.log 2>&1
+  rocprofv3 --pmc $pass --output-format csv -d $OUT/p$i -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary --no-frame-batch --min-timed-s 0.1 ${BENCH_ARGS} > $OUT/p$i.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections

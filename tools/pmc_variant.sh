@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for pass in "$@"; do
   i=$((i+1))
-  timeout -k 10 240 rocprofv3 --pmc $pass --output-format csv -d $OUT/p$i -- python3 $R/bench.py --config $CFG --steps 10 --warmup 2 --no-cpu-baseline --no-secondary --min-timed-s 0.1 > $OUT/p$i.log 2>&1 || echo "pass $i failed"
+  timeout -k 10 240 rocprofv3 --pmc $pass --output-format csv -d $OUT/p$i -- python3 $R/bench.py --config $CFG --steps 10 --warmup 2 --no-cpu-baseline --no-secondary --no-frame-batch --min-timed-s 0.1 > $OUT/p$i.log 2>&1 || echo "pass $i failed"
 done
 python3 - <<PY
 import csv, glob, collections
