@@ -426,6 +426,22 @@ class HipBackend:
                                             nat.ptr(image), st), "rtgs_untile_map")
 
 
+_STREAM_POOL = {}
+
+
+def _render_streams(device, count: int, offset: int):
+    """`count` render streams out of ONE pool per (process, device), starting at `offset`: renderers built one after the
+    other in a process (bench.py times five deals) share their streams instead of drawing new ones each -- which HIP
+    stream shares a hardware queue with which other is a matter of creation order, and a render stream that shares the
+    caller's queue serialises behind the exchange's event waits (round 5: the same rank's loop alternated between 25 and
+    28-35 us per c3 frame from one renderer to the next; ``TileParallelRenderer`` times the candidates once and keeps
+    the fastest set, ``_pick_render_streams``)."""
+    pool = _STREAM_POOL.setdefault((device.type, device.index), [])
+    while len(pool) < offset + count:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[offset:offset + count]
+
+
 def _pose_rows(poses):
     """(n, 7) float32 rows x y z qx qy qz qw from (position, rotation) pairs or an array of that shape."""
     import numpy as np
@@ -662,6 +678,7 @@ class TileParallelRenderer:
                 self._glist = [list(g.unbind(0)) for g in self.gathered]
             if streams:
                 self._comm = self._make_stream_state(F, B)
+                self._pick_render_streams()
 
     @property
     def framebuffer(self):
@@ -741,7 +758,7 @@ class TileParallelRenderer:
             ws = [b.workspace] + [torch.empty_like(b.workspace) for _ in range(F - 1)]
         images = (ctypes.c_void_p * len(self._fbs))(*[fb.data_ptr() for fb in self._fbs]) if self._fbs else None
         self._counts_c = (ctypes.c_int32 * self.world)(*self.partition.counts)
-        render = [torch.cuda.Stream(device=b.device) for _ in range(F)]
+        render = _render_streams(b.device, F, 0)
         done = [[event() for _ in range(F)] for _ in range(self._slots)]
         return dict(render=render, ws=ws, state=state, done=done,
                     done_c=[(ctypes.c_void_p * F)(*row) for row in done],
@@ -751,6 +768,51 @@ class TileParallelRenderer:
                     start_c=(ctypes.c_void_p * F)(*[nat.ptr(st) for _, st in state]) if state[0][0] is not None else None,
                     sent=[event() for _ in range(self._slots)], seen=[None] * F, turn=0,
                     params=params, order=order, images=images, g=0, lib=lib)
+
+    _PICKED = {}          # (device, F) -> offset into the stream pool of the set that timed fastest in this process
+
+    def _pick_render_streams(self) -> None:
+        """Which F streams of the process's pool render: the set under which THIS rank's loop -- render side and landing,
+        the exchange left out -- runs fastest, timed once per (process, device, F) over three candidate sets (48 frames
+        each, a few milliseconds).  HIP maps streams to hardware queues by creation order; a render stream that shares
+        its queue with the caller's stream waits behind the exchange's barrier packets.  RTGS_STREAM_PICK=0: the first set."""
+        import time
+        import ctypes
+        cm, b = self._comm, self.backend
+        F = self.frames_in_flight
+        key = (b.device.index, F)
+        if os.environ.get("RTGS_STREAM_PICK", "1") == "0" or self.frames_per_launch < 2 or not self.local_tiles:
+            return
+        if key not in TileParallelRenderer._PICKED:
+            saved = (self._a2a, self._gather, self._p2p_fn)
+            self._a2a, self._gather, self._p2p_fn = _no_all_to_all, _no_gather, (lambda mine, landing: [])
+            best = None
+            try:
+                for cand in range(3):
+                    rs = _render_streams(b.device, F, cand * F)
+                    cm["render"], cm["streams_c"] = rs, (ctypes.c_void_p * F)(*[x.cuda_stream for x in rs])
+                    cm["seen"] = [None] * F
+                    n = 6 * self.gather_batch
+                    self.render_frames(count=self.gather_batch)
+                    self.finish()
+                    torch.cuda.synchronize(b.device)
+                    t0 = time.perf_counter()
+                    self.render_frames(count=n)
+                    self.finish()
+                    torch.cuda.synchronize(b.device)
+                    dt = time.perf_counter() - t0
+                    if best is None or dt < best[0]:
+                        best = (dt, cand)
+            finally:
+                self._a2a, self._gather, self._p2p_fn = saved
+            TileParallelRenderer._PICKED[key] = best[1] * F
+            _phase("render streams: candidate set", best[1], "of 3")
+            self._frame = 0
+            self._landed_frames = []
+            cm["turn"] = 0
+        rs = _render_streams(b.device, F, TileParallelRenderer._PICKED[key])
+        cm["render"], cm["streams_c"] = rs, (ctypes.c_void_p * F)(*[x.cuda_stream for x in rs])
+        cm["seen"] = [None] * F
 
     def close(self) -> None:
         """Drain the render streams and release the events (also runs when the object is collected)."""

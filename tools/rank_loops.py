@@ -74,7 +74,13 @@ for name in (sys.argv[1:] or ["c3", "c5"]):
                             r = TileParallelRenderer(scene, camera, depth=cfg.depth, rank=rank, world=world, gather_fn=_no_gather,
                                                      p2p_fn=lambda mine, landing: [], a2a_fn=_no_all_to_all, partition=part,
                                                      frames_in_flight=F, gather_batch=B, landing=landing)
-                            per.append(loop_us(r, n)); host.append(host_us(r, n)); r.close()
+                            per.append(loop_us(r, n)); host.append(host_us(r, n))
+                            if os.environ.get("DEBUG_PTRS") and r._comm:
+                                cm = r._comm
+                                print(f"   rank {rank}: loop {per[-1]:.1f} us  ws " + " ".join(hex(w.data_ptr()) for w in cm["ws"]) + "  compact " +
+                                      " ".join(hex(c.data_ptr()) for c in r.compact) + "  gathered " + " ".join(hex(g.data_ptr()) for g in r.gathered) +
+                                      "  fbs " + " ".join(hex(f.data_ptr()) for f in r._fbs) + f"  ws bytes {cm['ws'][0].numel()}", flush=True)
+                            r.close()
                             Beff = r.gather_batch
                         worst = max(per)
                         shard = max(part.counts) * 256 * 12
