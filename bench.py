@@ -438,11 +438,12 @@ def rank_main(args) -> int:
     class BatchedSingle:
         """N = 1, G whole frames per launch: the adapter run_mode needs around rtgs.parallel.FrameBatchRenderer."""
 
-        def __init__(self, frames):
+        def __init__(self, frames, streams):
             from rtgs.parallel import FrameBatchRenderer
-            self.fb = FrameBatchRenderer(scene, camera, depth=cfg.depth, frames=frames)
+            self.fb = FrameBatchRenderer(scene, camera, depth=cfg.depth, frames=frames, streams=streams)
+            self.streams = streams
             self.one = TileParallelRenderer(scene, camera, depth=cfg.depth, rank=0, world=1)
-            self.gather_batch, self.frames_in_flight, self.landing = self.fb.frames, 1, "batch"
+            self.gather_batch, self.frames_in_flight, self.landing = self.fb.frames, 1, "batch" if streams == 1 else "batch2"
             self.partition, self.calibration, self.local_tiles = self.one.partition, None, self.one.local_tiles
 
         def render_frames(self, poses=None, count=None):
@@ -482,8 +483,8 @@ def rank_main(args) -> int:
         from rtgs.parallel import _phase
         partition, landing, gbatch = mode
         _phase("bench: mode", mode)
-        if world == 1 and landing == "batch":
-            renderer = BatchedSingle(gbatch)
+        if world == 1 and landing in ("batch", "batch2"):
+            renderer = BatchedSingle(gbatch, 2 if landing == "batch2" else 1)
         else:
             renderer = TileParallelRenderer(scene, camera, depth=cfg.depth, rank=rank, world=world, partition=partition,
                                             landing=landing, gather_batch=gbatch if world > 1 else None)
@@ -560,7 +561,9 @@ def rank_main(args) -> int:
         # and eight poses per launch of each kernel (rtgs.parallel.FrameBatchRenderer: every frame fully projected, binned
         # and traced into a framebuffer of its own, each verified bit for bit against its single-frame render); `value`
         # is the faster verified one, the other stays under `secondary`
-        modes = [("equal", "root", None)] + ([] if args.no_frame_batch else [("equal", "batch", 8)])
+        # (the batches on one stream, or alternating over two so that the next batch's projection runs under this batch's
+        # trace: pays for short frames -- c2 -- and not at c3)
+        modes = [("equal", "root", None)] + ([] if args.no_frame_batch else [("equal", "batch", 8), ("equal", "batch2", 8)])
     else:
         if "," in args.partition:
             parts = [tuple(float(v) for v in args.partition.split(","))]
@@ -633,9 +636,11 @@ def rank_main(args) -> int:
         metric = base_metric if (cfg.width, cfg.height, cfg.n) == (1920, 1080, 100_000) else \
             f"Mrays/s at {cfg.width}x{cfg.height}, {cfg.n} Gaussians; achieved HBM GB/s vs peak"
         comm = ""
-        if world == 1 and best["landing"] == "batch":
+        if world == 1 and best["landing"] in ("batch", "batch2"):
             comm = (f", {best['gather_batch']} whole frames per launch of each kernel (rtgs_shard_frames: every frame projected, "
-                    "binned and traced into a framebuffer of its own; secondary.single_gpu_modes has the one-frame-per-launch loop)")
+                    "binned and traced into a framebuffer of its own" +
+                    ("; batches alternate over two streams" if best["landing"] == "batch2" else "") +
+                    "; secondary.single_gpu_modes has the one-frame-per-launch loop)")
         if world > 1:
             what = "all_to_all to rotating roots (every rank lands 1/N of the frames)" if best["landing"] == "rotate" else "gather to rank 0"
             comm = f" + RCCL {what}" if args.backend == "nccl" else f" + {args.backend} {what} (rehearsal, not RCCL)"
@@ -754,7 +759,8 @@ def rank_main(args) -> int:
         part, landing, gbatch = m
         part = part if isinstance(part, str) else ",".join(f"{v:g}" for v in part)
         if world == 1:
-            return "one frame per launch" if landing != "batch" else f"{gbatch} frames per launch"
+            return ("one frame per launch" if landing not in ("batch", "batch2") else
+                    f"{gbatch} frames per launch" + (", batches alternating over 2 streams" if landing == "batch2" else ""))
         return f"{part}/{landing}/B{gbatch}"
 
     def pick(pool_of):

@@ -472,31 +472,53 @@ class FrameBatchRenderer:
     """Whole frames on ONE GPU, up to `frames` consecutive poses per LAUNCH (grid.y = frames through
     ``rtgs_shard_frames``): a turntable or a benchmark that knows its next poses pays one k_project / k_bin / k_trace
     launch -- and their latency-bound heads and tails -- per batch instead of per frame (c3: the three launches of a
-    frame are 0.147 ms one by one, of which k_project + k_bin are 17 us of mostly latency).  Every frame is fully
-    projected, binned and traced; ``images[k]`` is frame k of the last ``render_frames`` call, complete in the
-    caller's stream order.  The reference's viewer renders one pose per loop iteration (__main__.py:236-257): this is
-    for consumers that take frames in batches, at frames - 1 frames of latency."""
+    frame are 0.147 ms one by one, of which k_project + k_bin are 17 us of mostly latency).  ``streams=2``: consecutive
+    calls alternate over two render streams, each with a workspace and a set of images of its own, so that batch k + 1's
+    projection and bins run under batch k's trace -- pays for short frames (c2: 0.0295 -> 0.0264 ms per frame) and not
+    at c3 (0.1318 -> 0.1343: what a dependency across two hardware queues costs, again).  Every
+    frame is fully projected, binned and traced; ``images[k]`` is frame k of the LAST ``render_frames`` call, complete
+    in the caller's stream order, and stays valid until the call after the next.  The reference's viewer renders one
+    pose per loop iteration (__main__.py:236-257): this is for consumers that take frames in batches, at frames - 1
+    frames of latency."""
 
-    def __init__(self, scene, camera, depth: int = 16, frames: int = 8, t_cutoff: float = 0.0):
+    def __init__(self, scene, camera, depth: int = 16, frames: int = 8, t_cutoff: float = 0.0, streams: int = 1):
         import ctypes
         self.backend = b = HipBackend(scene, camera, depth, t_cutoff)
         nat = b.nat
         lib = nat.lib()
         self.frames = max(1, min(int(frames), lib.rtgs_max_frames_per_launch()))
-        self.images = b.alloc(self.frames, b.width, b.height, 3)
+        self._n = S = max(1, int(streams))
+        self._images = [b.alloc(self.frames, b.width, b.height, 3) for _ in range(S)]
         need = lib.rtgs_workspace_bytes_frames(scene.num_gaussians, b.width, b.height, self.frames)
-        self._ws = torch.empty(need, dtype=torch.uint8, device=b.device)
+        self._ws = [torch.empty(need, dtype=torch.uint8, device=b.device) for _ in range(S)]
         order = b.tile_order(0, 1) if b.use_tile_order else None
         self._params = nat.RtgsTraceParams(b.depth, b.t_cutoff, 0, 1, 0, nat.ptr(order))
         self._order = order
-        h = ctypes.c_void_p()
-        nat.check(lib.rtgs_event_create(ctypes.byref(h)), "rtgs_event_create")
-        self._event = h.value
-        self._done_c = (ctypes.c_void_p * 1)(self._event)
-        self._ws_c = (ctypes.c_void_p * 1)(self._ws.data_ptr())
-        stride = self.images.stride(0) * 4
-        self._outs_c = (ctypes.c_void_p * self.frames)(*[self.images.data_ptr() + k * stride for k in range(self.frames)])
-        self._lib = lib
+
+        def event():
+            h = ctypes.c_void_p()
+            nat.check(lib.rtgs_event_create(ctypes.byref(h)), "rtgs_event_create")
+            return h.value
+
+        self._done = [event() for _ in range(S)]
+        # free[k]: "the caller's stream is past everything it queued on set k's images" -- recorded at the START of the
+        # call after the one that rendered set k, i.e. behind that batch's consumers but AHEAD of the wait for the next
+        # batch's trace, so that the batch after next can start projecting while that trace still runs
+        self._free = [torch.cuda.Event() for _ in range(S)]
+        self._free_set = [False] * S
+        self._streams = _render_streams(b.device, S, 0) if S > 1 else None
+        self._done_c = [(ctypes.c_void_p * 1)(e) for e in self._done]
+        self._ws_c = [(ctypes.c_void_p * 1)(w.data_ptr()) for w in self._ws]
+        self._outs_c = []
+        for img in self._images:
+            stride = img.stride(0) * 4
+            self._outs_c.append((ctypes.c_void_p * self.frames)(*[img.data_ptr() + k * stride for k in range(self.frames)]))
+        self._lib, self._turn, self._last, self._seen = lib, 0, 0, [None] * S
+
+    @property
+    def images(self):
+        """(frames, W, H, 3): the images of the last ``render_frames`` call."""
+        return self._images[self._last]
 
     def render_frames(self, poses=None, count: int | None = None) -> int:
         """Render up to `frames` poses ((position, rotation) pairs or (n, 7) rows; default: `count` copies of the
@@ -508,17 +530,37 @@ class FrameBatchRenderer:
         if n < 1 or n > self.frames:
             raise ValueError(f"1 .. {self.frames} frames per call")
         cams, _ = b.camera_array(rows, n)
-        streams = (ctypes.c_void_p * 1)(nat.stream())
-        nat.check(self._lib.rtgs_shard_frames(b.scene_native(), cams.ctypes.data, n, self._params, self._outs_c, None, None,
-                                              self._ws_c, self._ws.numel(), streams, 1, 0, None, self._done_c, None, 0),
-                  "rtgs_shard_frames")
+        k = self._turn % self._n
+        self._turn += 1
+        cur = nat.stream()
+        if self._streams is None:
+            st = cur
+        else:
+            rs = self._streams[k]
+            st = rs.cuda_stream
+            key = b.scene.content_key()
+            if self._seen[k] != key:       # scene uploads / edits queued on the caller's stream
+                rs.wait_stream(nat.current_stream(b.device.index))
+                self._seen[k] = key
+            if self._turn > 1:
+                prev = (k - 1) % self._n
+                self._free[prev].record(nat.current_stream(b.device.index))
+                self._free_set[prev] = True
+        streams = (ctypes.c_void_p * 1)(st)
+        nat.check(self._lib.rtgs_shard_frames(b.scene_native(), cams.ctypes.data, n, self._params, self._outs_c[k], None, None,
+                                              self._ws_c[k], self._ws[k].numel(), streams, 1, 0,
+                                              self._free[k].cuda_event if (self._streams is not None and self._free_set[k]) else None,
+                                              self._done_c[k],
+                                              cur, 1 if self._streams is not None else 0), "rtgs_shard_frames")
+        self._last = k
         return n
 
     def close(self) -> None:
-        ev, self._event = self._event, None
-        if ev is not None:
+        evs, self._done = self._done, []
+        if evs:
             torch.cuda.synchronize(self.backend.device)
-            self._lib.rtgs_event_destroy(ev)
+            for e in evs:
+                self._lib.rtgs_event_destroy(e)
 
     def __del__(self):
         try:

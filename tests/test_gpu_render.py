@@ -1304,8 +1304,9 @@ def test_rotating_roots_land_their_frames_bit_exact_without_host_syncs(rank, in_
     r0.close()
 
 
+@pytest.mark.parametrize("streams", [1, 2])
 @pytest.mark.parametrize("name", ["oblique", "sh", "mid_sh"])
-def test_whole_frames_batched_on_one_gpu_equal_single_frames(name):
+def test_whole_frames_batched_on_one_gpu_equal_single_frames(name, streams):
     # FrameBatchRenderer: up to eight poses per launch on ONE GPU (whole frames, image layout): each image must equal
     # the single-frame render of its pose bit for bit, also for a short batch and for the camera's own pose
     from rtgs.parallel import FrameBatchRenderer
@@ -1319,8 +1320,8 @@ def test_whole_frames_batched_on_one_gpu_equal_single_frames(name):
     p0 = np.asarray(cam["position"], np.float64)
     rng = np.random.default_rng(9)
     poses = [(tuple(p0 + d), tuple(cam["rotation"])) for d in rng.uniform(-0.25, 0.25, (8, 3))]
-    fb = FrameBatchRenderer(scene, camera, depth=depth, frames=8)
-    for batch in (poses, poses[:3]):
+    fb = FrameBatchRenderer(scene, camera, depth=depth, frames=8, streams=streams)
+    for batch in (poses, poses[:3], poses[2:7], poses):
         assert fb.render_frames(batch) == len(batch)
         torch.cuda.synchronize()
         for k, (pos, rot) in enumerate(batch):
