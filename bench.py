@@ -347,6 +347,10 @@ def main(argv=None) -> int:
 
 def rank_main(args) -> int:
     global np, torch, dist
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # N > 1: the caller's stream, two render streams and RCCL's own all want a hardware queue; HIP's default is four
+        # per process, beyond which streams share (read when the runtime initialises: set before torch is imported)
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import datetime
     import numpy as np
     import torch
