@@ -98,6 +98,13 @@ def fuzz_case(seed):
     depth = int(rng.integers(1, 17))
     world = int(rng.choice([1, 1, 2, 5, 8]))
     mode = int(rng.integers(0, 4))
+    # (round 5, drawn last so that every earlier field of a seed is what it was) NON-UNIT quaternions, as the reference
+    # takes them: Gaussian.init does not normalise (gaussian.py:59-84) and rot_vec3 of a non-unit camera quaternion
+    # stretches the ray directions by |q|^2 (camera.py:52) -- the class of input behind round 5's horizon-bound bug
+    if rng.random() < 0.3:
+        cam["rotation"] = f32_tuple(np.asarray(cam["rotation"]) * rng.uniform(0.75, 1.35))
+    if rng.random() < 0.3:
+        arrays["rotation"] = (arrays["rotation"] * rng.uniform(0.7, 1.4, (arrays["rotation"].shape[0], 1))).astype(np.float32)
     return arrays, cam, depth, world, mode
 
 
