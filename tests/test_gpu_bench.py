@@ -130,3 +130,51 @@ def test_two_ranks_over_rccl(extra):
     out, line = _run(["--gpus", "2", "--steps", "20", "--warmup", "5", "--config", "c2", *extra])
     assert out.returncode == 0, out.stderr[-2000:]
     assert line["verified"] is True and "RCCL" in line["config"]["parallelism"]
+
+
+def test_rccl_accepts_the_collectives_as_the_frame_loop_calls_them():
+    # No N > 1 hardware has ever met this code; what CAN be checked on one GPU is that RCCL itself -- a one-rank "nccl"
+    # group -- takes the exchange calls exactly as rtgs.parallel issues them: all_to_all_single on the batch buffers
+    # (equal split of a 5-D tensor; flat tensors with explicit split sizes), gather into unbound views, an empty
+    # batch_isend_irecv, the all-reduced verdict.  (Two ranks on one device are refused by RCCL: that is the rehearsal's
+    # gloo path above.)
+    code = r'''
+import os, sys, datetime
+sys.path[:0] = [os.path.join(r"%s", "rt-gaussian-splat-renderer_amd"), r"%s"]
+import torch, torch.distributed as dist
+from rtgs.parallel import _all_to_all
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, timeout=datetime.timedelta(seconds=120))
+send = torch.arange(8 * 5 * 16 * 16 * 3, dtype=torch.float32, device=dev).reshape(8, 5, 16, 16, 3)
+recv = torch.zeros_like(send)
+_all_to_all(recv, send, None, None, group=None)
+torch.cuda.synchronize()
+assert torch.equal(recv, send)
+flat_in, flat_out = send.reshape(-1), torch.zeros(send.numel() + 7, dtype=torch.float32, device=dev)
+_all_to_all(flat_out[:send.numel()], flat_in, [send.numel()], [send.numel()], group=None)
+torch.cuda.synchronize()
+assert torch.equal(flat_out[:send.numel()], flat_in) and float(flat_out[send.numel():].abs().sum()) == 0.0
+gathered = torch.zeros((1, 8, 5, 16, 16, 3), dtype=torch.float32, device=dev)
+dist.gather(send, gather_list=list(gathered.unbind(0)), dst=0, async_op=False)
+torch.cuda.synchronize()
+assert torch.equal(gathered[0], send)
+flag = torch.tensor([1], dtype=torch.int32, device=dev)
+dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+t = torch.tensor([1.5], dtype=torch.float64, device=dev)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+assert int(flag.item()) == 1 and float(t.item()) == 1.5
+rows = [None]
+dist.all_gather_object(rows, {"rank": 0})
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL_OK")
+''' % (ROOT, ROOT)
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    e.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=e, cwd=ROOT)
+    assert out.returncode == 0 and "RCCL_OK" in out.stdout, out.stderr[-2000:]
