@@ -768,11 +768,16 @@ __global__ __launch_bounds__(256) void k_bin(int32_t nslabs, const float4* __res
         const int tx = (st % bin_sx) * per_edge + (t % per_edge), ty = (st / bin_sx) * per_edge + (t / per_edge);
         const bool in = t < ntl && tx < tiles_x && ty < tiles_y && (!restricted || owned(tx, ty));
         const int mi0 = tx * kTile, mj0 = ty * kTile;
-        // (a tile outside the frame gets bounds nothing overlaps and no output)
-        tXlo[q] = in ? ((float)mi0 + 0.5f) - hw : kInf;
-        tXhi[q] = in ? ((float)min(mi0 + kTile, width) - 0.5f) - hw : -kInf;
-        tYlo[q] = in ? ((float)mj0 + 0.5f) - hh : kInf;
-        tYhi[q] = in ? ((float)min(mj0 + kTile, height) - 0.5f) - hh : -kInf;
+        // (a tile outside the frame, or not this shard's, gets no output and bounds NOTHING overlaps: NaN, every
+        // compare false.  Round 4's (+inf, -inf) "empty" bounds were overlapped by the (-inf .. +inf) box of a slab
+        // with a Gaussian around the camera (k_project), whose id then went to out[q] = NULL: a write to address 4
+        // whenever such a slab met a frame whose tile grid is not whole supertiles -- found in round 5 by the
+        // tile-parallel fuzzer, 200 x 1 pixels with the camera inside a Gaussian)
+        const float none = __builtin_nanf("");
+        tXlo[q] = in ? ((float)mi0 + 0.5f) - hw : none;
+        tXhi[q] = in ? ((float)min(mi0 + kTile, width) - 0.5f) - hw : none;
+        tYlo[q] = in ? ((float)mj0 + 0.5f) - hh : none;
+        tYhi[q] = in ? ((float)min(mj0 + kTile, height) - 0.5f) - hh : none;
         out[q] = in ? tile_bin + (size_t)(ty * tiles_x + tx) * kTileBinCap : nullptr;
         n[q] = 0;
       }
@@ -786,7 +791,7 @@ __global__ __launch_bounds__(256) void k_bin(int32_t nslabs, const float4* __res
           const bool keep = b.x <= tXhi[q] && b.z >= tXlo[q] && b.y <= tYhi[q] && b.w >= tYlo[q];
           const unsigned long long km2 = __ballot(keep);
           const int at = n[q] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(km2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km2, 0u));
-          if (keep && at < kTileBinCap - 1) out[q][1 + at] = id;
+          if (keep && out[q] && at < kTileBinCap - 1) out[q][1 + at] = id;
           n[q] += __popcll(km2);
         }
       }
@@ -2643,8 +2648,12 @@ int rtgs_shard_frames(const RtgsScene* scene, const RtgsCamera* cams, int32_t n_
                              static_cast<hipEvent_t>(reuse_event), 0) != hipSuccess)
         return RTGS_EDEVICE;
   }
-  // an EMPTY share (explicit tile list of no tiles) renders nothing: its frames only take part in the event chain
-  const bool empty_share = params && (params->flags & RTGS_TRACE_TILE_LIST) && params->tile_count == 0;
+  // an EMPTY share (an explicit tile list of no tiles; more ranks than the frame has tiles) renders nothing: its frames
+  // only take part in the event chain
+  const bool empty_share = params && ((params->flags & RTGS_TRACE_TILE_LIST)
+                                          ? params->tile_count == 0
+                                          : (cams[0].width > 0 && cams[0].height > 0 && params->tile_step > 0 && params->tile_first >= 0 &&
+                                             rtgs_num_local_tiles(cams[0].width, cams[0].height, params->tile_first, params->tile_step) == 0));
   // Frames that can share a launch: consecutive frames of one stream whose outputs are equally spaced, when the
   // stream's workspace has room for their regions (rtgs_workspace_bytes_frames) -- ONE k_project, k_bin and k_trace
   // with grid.y = frames instead of one latency-bound chain of small launches per frame: a 1/8 shard of a 1080p frame

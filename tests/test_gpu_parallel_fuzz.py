@@ -1,0 +1,96 @@
+"""-m gpu: seeded random configurations of the tile-parallel render side (round 5's new code: frames per call, frames
+per launch, rotating roots, explicit deals, per-shard bins, the region cull, the stream pick).  For a random rank of a
+random world, a random deal / landing / batch / frames in flight and random poses handed over in random portions, every
+frame's shard in the batch buffer the rank would SEND must equal, bit for bit, the direct single-frame render of that
+shard at that pose -- whatever the image size (down to fewer tiles than ranks) and the scene size (with and without
+bins, one- and two-level scans, SH staged or gathered)."""
+
+import numpy as np
+import pytest
+import torch
+
+import gpu_util as U
+from rtgs import _native as nat
+from rtgs import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def parallel_case(seed):
+    rng = np.random.default_rng(seed)
+    w, h = int(rng.choice([1, 17, 33, 64, 100, 161, 200])), int(rng.choice([1, 16, 40, 90, 128]))
+    n = int(rng.choice([1, 65, 700, 5000, 40_000, 40_000, 270_000]))
+    sh = bool(rng.random() < 0.35)
+    arrays = synthetic.make_scene(n, max(w / h, 0.2), seed, sh=sh)
+    arrays["scale"] = (arrays["scale"] * np.float32(rng.choice([0.5, 1.0, 3.0]))).astype(np.float32)
+    cam = synthetic.bench_camera(w, h)
+    world = int(rng.choice([2, 3, 4, 5, 8]))
+    rank = int(rng.integers(0, world))
+    landing = str(rng.choice(["root", "rotate"]))
+    batch = int(rng.choice([1, 2, 3, 5, 8]))
+    in_flight = int(rng.choice([1, 2, 3]))
+    deal = rng.choice(["equal", "equal", "wedges", "weighted"])
+    shares = None
+    if deal == "weighted":
+        shares = [float(v) for v in rng.choice([0.0, 1.0, 2.0, 5.0], world)]
+        if sum(shares) == 0:
+            shares[int(rng.integers(0, world))] = 1.0
+    n_poses = int(rng.integers(1, 14))
+    p0 = np.asarray(cam["position"], np.float64)
+    poses = [(tuple(p0 + d), tuple(cam["rotation"])) for d in rng.uniform(-0.3, 0.3, (n_poses, 3))]
+    portions, left = [], n_poses
+    while left:
+        k = int(rng.integers(1, left + 1))
+        portions.append(k)
+        left -= k
+    depth = int(rng.choice([1, 3, 16, 16, 16]))
+    return dict(arrays=arrays, cam=cam, world=world, rank=rank, landing=landing, batch=batch, in_flight=in_flight,
+                deal=str(deal), shares=shares, poses=poses, portions=portions, depth=depth)
+
+
+def run_parallel_case(seed):
+    from rtgs.parallel import HipBackend, Partition, TileParallelRenderer, _no_all_to_all, _no_gather
+    from rtgs.utils.types import vec3
+    c = parallel_case(seed)
+    scene, camera, _ = U.build(c["arrays"], c["cam"])
+    w, h, T = c["cam"]["width"], c["cam"]["height"], nat.tile_size()
+    total = nat.lib().rtgs_num_tiles(w, h)
+    part = {"equal": None, "wedges": "wedges"}.get(c["deal"], c["shares"])
+    r = TileParallelRenderer(scene, camera, depth=c["depth"], rank=c["rank"], world=c["world"], landing=c["landing"],
+                             gather_batch=c["batch"], frames_in_flight=c["in_flight"], partition=part,
+                             gather_fn=_no_gather, p2p_fn=lambda mine, landing: [], a2a_fn=_no_all_to_all)
+    B = r.gather_batch
+    for buf in r.compact:
+        buf.fill_(-3.0)
+    at = 0
+    for k in c["portions"]:
+        r.render_frames(c["poses"][at:at + k])
+        at += k
+    r.finish()
+    torch.cuda.synchronize()
+    hb = HipBackend(scene, camera, c["depth"])
+    shard = None if r.partition.arithmetic else hb.shard(r.partition.tiles[c["rank"]], region=r.partition.compact)
+    n = len(c["poses"])
+    last0 = (n - 1) // B * B                      # the frames of the last batch are still in the ring
+    checked = 0
+    for f in range(last0, n):
+        slot = (f // B) % r._slots
+        got = r.compact[slot][f % B] if r.compact[slot].dim() == 5 else r.compact[slot]
+        if r.local_tiles == 0:
+            assert bool((got == -3.0).all()), f"seed {seed}: an empty share wrote something"
+            continue
+        camera.position = vec3(c["poses"][f][0])
+        want = torch.full_like(got, -3.0)
+        hb.trace(want, c["rank"], c["world"], compact=True, shard=shard)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), (f"seed {seed}: frame {f} of {n}, rank {c['rank']}/{c['world']}, {c['landing']}, B {B}, "
+                                        f"F {c['in_flight']}, deal {c['deal']}, {w}x{h}, n {c['arrays']['position'].shape[0]}")
+        checked += 1
+    r.close()
+    return checked, r.local_tiles, total
+
+
+# 9194: the soak's find (a 200 x 1 frame, the camera inside a Gaussian: k_bin wrote through a NULL tile list)
+@pytest.mark.parametrize("seed", [*range(5000, 5040), 9194])
+def test_random_tile_parallel_render_sides(seed):
+    run_parallel_case(seed)

@@ -166,6 +166,32 @@ def test_large_scene_instantiation(sh):
     print(f"large scene sh={sh}: max |err| {worst:.2e}")
 
 
+@pytest.mark.parametrize("size", [(200, 40), (200, 1), (72, 136)])
+def test_gaussians_across_the_camera_plane_in_a_frame_of_partial_supertiles(size):
+    # regression (tools/fuzz_parallel.py seed 9194, round 5): a slab holding a Gaussian that CROSSES the camera plane
+    # (its outline is a hyperbola: k_project keeps it without a bound) has the bounds (-inf .. +inf); k_bin's per-tile
+    # lists gave the tiles of a supertile that lie outside the frame "empty" bounds (+inf, -inf), which that box
+    # overlaps, and listed the slab into a NULL list -- a GPU memory fault whenever the frame's tile grid is not whole
+    # supertiles (4 x 4 tiles) and the scene is large enough for bins
+    w, h = size
+    n = 40_000
+    arrays = synthetic.make_scene(n, max(w / h, 0.2), 5152)
+    cam = synthetic.bench_camera(w, h)
+    # six spheres of radius 0.8 sqrt(3) = 1.39 at distance 1.5 from the camera along the world axes: the camera is
+    # outside all of them, and whatever its orientation at least two reach across its plane
+    for k, off in enumerate(np.concatenate([np.eye(3), -np.eye(3)]) * 1.5):
+        arrays["position"][n // 2 + 64 * k] = np.asarray(cam["position"], np.float32) + off.astype(np.float32)
+        arrays["scale"][n // 2 + 64 * k] = 0.8
+    _, _, tracer = U.build(arrays, cam)
+    tracer.sample_all(16)
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(3)
+    pix = np.stack([rng.integers(0, w, 1500), rng.integers(0, h, 1500)], axis=-1).astype(np.int32)
+    want = c_oracle.render(arrays, cam, 16, pix)
+    U.assert_parity(U.at(tracer.sample_buf, pix), want, f"Gaussians across the camera plane, {w}x{h}")
+    assert want["hits"].mean() > 4
+
+
 def test_very_large_scene_two_outer_scan_steps():
     # Tune<true> scans bounds of 16-slab groups first, 1024 groups per step: more than
     # 1024 * 16 * 64 = 1 048 576 Gaussians takes a second outer step of that two-level scan
