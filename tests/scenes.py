@@ -108,6 +108,36 @@ def fuzz_case(seed):
     return arrays, cam, depth, world, mode
 
 
+def big_fuzz_case(seed):
+    """tools/fuzz_big.py generator (round 5): what fuzz_case never reached -- scenes large enough for the per-frame
+    slab BINS (>= 513 slabs = 32 832 Gaussians; k_bin, the per-tile lists, their overflow fall-backs) and for the
+    two-level scan (> 4096 slabs), under random cameras from inside the cloud to 8 units away, any orientation, image
+    sizes 1..260 x 1..160 (tile grids that are not whole supertiles), scale multipliers 0.3..3, needles, SH, non-unit
+    quaternions, sharded traces.  Returns (arrays, cam, depth, world, pixels): the oracle is evaluated on `pixels`."""
+    rng = np.random.default_rng(seed)
+    w, h = int(rng.integers(1, 261)), int(rng.integers(1, 161))
+    n = int(rng.choice([32_832, 33_000, 50_000, 66_000, 140_000, 270_000]))
+    sh = bool(rng.random() < 0.25)
+    arrays = synthetic.make_scene(n, max(w / h, 0.2), seed, sh=sh)
+    arrays["scale"] = (arrays["scale"] * np.float32(rng.choice([0.3, 1.0, 3.0]))).astype(np.float32)
+    if rng.random() < 0.2:
+        arrays["scale"][:, int(rng.integers(0, 3))] *= np.float32(rng.uniform(3, 10))
+    rot = quat_axis_angle(rng.normal(size=3), rng.uniform(0, 3.1))
+    pos = f32_tuple(rng.normal(size=3) * rng.choice([0.2, 1.0, 3.0, 8.0]))
+    f = float(np.float32(rng.uniform(0.3, 3.0) * max(h, 8)))
+    cam = dict(position=pos, rotation=rot, width=w, height=h, fx=f, fy=float(np.float32(f * rng.uniform(0.7, 1.4))))
+    depth = int(rng.integers(1, 17))
+    world = int(rng.choice([1, 1, 2, 5, 8]))
+    if rng.random() < 0.2:
+        cam["rotation"] = f32_tuple(np.asarray(cam["rotation"]) * rng.uniform(0.75, 1.35))
+    if rng.random() < 0.2:
+        arrays["rotation"] = (arrays["rotation"] * rng.uniform(0.7, 1.4, (n, 1))).astype(np.float32)
+    k = min(w * h, 900)
+    flat = rng.choice(w * h, k, replace=False)
+    pixels = np.stack([flat // h, flat % h], axis=-1).astype(np.int32)
+    return arrays, cam, depth, world, pixels
+
+
 def needle_case(seed):
     """tools/fuzz_needles.py generator: capture-like Gaussians, log-uniform scales, anisotropy up
     to ~300:1 (sub-pixel-wide needles), random camera.  Returns (arrays, cam)."""

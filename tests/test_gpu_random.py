@@ -86,6 +86,33 @@ def test_non_unit_quaternions_follow_the_reference_formulas(seed):
         assert part.compact and torch.equal(image, tracer.sample_buf), f"seed {seed} depth {d}: sectors with the region cull"
 
 
+def run_big_case(seed):
+    """One scenes.big_fuzz_case: the frame traced in `world` shards, sampled pixels against the C oracle.  Returns
+    (worst robust-pixel error, fragile pixels, pixels)."""
+    import rtgs
+    arrays, cam, depth, world, pix = scenes.big_fuzz_case(seed)
+    w, h = cam["width"], cam["height"]
+    scene = rtgs.Scene.from_arrays(**arrays)
+    camera = rtgs.Camera(cam["position"], cam["rotation"], (w, h), (cam["fx"], cam["fy"]))
+    tr = rtgs.RayTracer((w, h), scene, camera)
+    for r in range(world):
+        tr.trace(depth, tile_first=r, tile_step=world)
+    torch.cuda.synchronize()
+    got = U.at(tr.sample_buf, pix)
+    want = c_oracle.render(arrays, cam, depth, pix, eps_q=1e-4 if arrays["scale"].max() > 1 else 1e-5)
+    assert np.isfinite(got).all(), f"seed {seed}: non-finite pixels"
+    err = np.abs(got - want["sample"]).max(axis=1)
+    solid = ~want["fragile"]
+    return (float(err[solid].max()) if solid.any() else 0.0), int((~solid).sum()), int(err.size)
+
+
+@pytest.mark.parametrize("seed", range(12000, 12012))
+def test_random_large_scenes_and_cameras(seed):
+    # the bins / per-tile lists / two-level scan under random cameras (tools/fuzz_big.py soaks the same generator)
+    e, _, _ = run_big_case(seed)
+    assert e <= U.PIXEL_TOL, f"seed {seed}: max |err| {e:.3e}"
+
+
 def test_non_finite_gaussians_are_culled():
     # documented deviation (DESIGN.md 1): NaN / inf / zero-scale Gaussians never hit instead of
     # poisoning pixels with NaN as the reference's arithmetic would
