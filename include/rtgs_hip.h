@@ -272,7 +272,11 @@ int rtgs_event_query(void* event);
  * or NULL -- the previous reader of `out`] -> rtgs_project + rtgs_trace of the shard on render_stream
  * (as rtgs_trace with projected = 0, ray_start_stride 1; attenuation_buf / ray_start only needed for
  * depth > RTGS_MAX_DEPTH) -> traced_event recorded on render_stream -> [consumer_stream made to wait
- * for it when consumer_waits != 0; it is an argument of its own because the NULL stream is a stream]. */
+ * for it when consumer_waits != 0; it is an argument of its own because the NULL stream is a stream].
+ * The projection this call (and rtgs_shard_frames) leaves in `workspace` serves THIS shard only: its slab bins are
+ * built for the shard's own tiles (and, with RTGS_TRACE_REGION, its Gaussians culled to the region).  Tracing other
+ * tiles from it (rtgs_trace with projected = 1) is undefined; rtgs_project / rtgs_trace(projected = 0) keep
+ * whole-frame bins for that. */
 int rtgs_shard_frame(const RtgsScene* scene, const RtgsCamera* cam, const RtgsTraceParams* params,
                      float* out, float* attenuation_buf, float* ray_start, void* workspace, size_t workspace_bytes,
                      rtgs_stream_t render_stream, void* reuse_event, void* traced_event,

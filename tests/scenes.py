@@ -113,7 +113,8 @@ def big_fuzz_case(seed):
     slab BINS (>= 513 slabs = 32 832 Gaussians; k_bin, the per-tile lists, their overflow fall-backs) and for the
     two-level scan (> 4096 slabs), under random cameras from inside the cloud to 8 units away, any orientation, image
     sizes 1..260 x 1..160 (tile grids that are not whole supertiles), scale multipliers 0.3..3, needles, SH, non-unit
-    quaternions, sharded traces.  Returns (arrays, cam, depth, world, pixels): the oracle is evaluated on `pixels`."""
+    quaternions, sharded traces.  Returns (arrays, cam, depth, world, pixels): the oracle is evaluated on `pixels`;
+    world == 0 asks for the reference's one-peel-per-sample() pattern instead of a sharded trace."""
     rng = np.random.default_rng(seed)
     w, h = int(rng.integers(1, 261)), int(rng.integers(1, 161))
     n = int(rng.choice([32_832, 33_000, 50_000, 66_000, 140_000, 270_000]))
@@ -135,6 +136,10 @@ def big_fuzz_case(seed):
     k = min(w * h, 900)
     flat = rng.choice(w * h, k, replace=False)
     pixels = np.stack([flat // h, flat % h], axis=-1).astype(np.int32)
+    # (drawn last) one case in four in the reference's call pattern: `depth` sample() calls of one peel each -- the
+    # listing instantiation of k_trace and k_peel instead of the compositing one
+    if rng.random() < 0.25:
+        world = 0
     return arrays, cam, depth, world, pixels
 
 

@@ -95,6 +95,8 @@ def run_big_case(seed):
     scene = rtgs.Scene.from_arrays(**arrays)
     camera = rtgs.Camera(cam["position"], cam["rotation"], (w, h), (cam["fx"], cam["fy"]))
     tr = rtgs.RayTracer((w, h), scene, camera)
+    for _ in range(depth if world == 0 else 0):
+        tr.sample(depth)
     for r in range(world):
         tr.trace(depth, tile_first=r, tile_step=world)
     torch.cuda.synchronize()
