@@ -93,10 +93,12 @@ typedef struct RtgsCamera {
 #define RTGS_TRACE_REGION 64u     /* the shard's tiles all lie inside RtgsTraceParams.region: the projection this call
                                      runs skips the Gaussians that cannot reach it (same pixels) */
 
-/* scheduling only, same pixels: force / forbid the per-frame slab bins (k_bin) for this call's own projection.  By
- * default a shard below a sixth of the frame scans for itself -- right for ONE such launch on an idle chip (k_bin's
- * latency is longer than what its lists save a lone resident round of tiles), wrong once several frames' shards are in
- * flight and the chip is throughput-bound (rtgs.parallel with frames_in_flight >= 2 sets BINS_ON) */
+/* RTGS_TRACE_BINS_OFF: this call's own projection builds no per-frame slab bins (k_bin); its tiles scan the slab bounds
+ * themselves.  For experiments: a tile that scans lists its slabs in another order than its bin holds them, and the
+ * arrival order decides which of two EXACTLY tied entries a ray composites -- a shard rendered with the flag and one
+ * without may differ in such a pixel (everywhere else bit for bit the same).  Without the flag every projection of a
+ * scene large enough for bins builds them, whatever the shard (up to round 4 shards below a sixth of the frame did not;
+ * RTGS_TRACE_BINS_ON, which forced them, is accepted and ignored). */
 #define RTGS_TRACE_BINS_ON 128u
 #define RTGS_TRACE_BINS_OFF 256u
 
@@ -215,8 +217,8 @@ int rtgs_project(const RtgsScene* scene, const RtgsCamera* cam, void* workspace,
                  size_t workspace_bytes, rtgs_stream_t stream);
 
 /* rtgs_project exactly as rtgs_trace(projected = 0) would run it for the shard (tile_first,
- * tile_step): the supertile bins are only built when the shard is large enough for them to pay.
- * For callers that run a shard's projection apart from its trace (rtgs_trace with projected = 1). */
+ * tile_step) -- since round 5 the same as rtgs_project (whole-frame bins whatever the shard); kept for callers that
+ * run a shard's projection apart from its trace (rtgs_trace with projected = 1). */
 int rtgs_project_shard(const RtgsScene* scene, const RtgsCamera* cam, int32_t tile_first,
                        int32_t tile_step, void* workspace, size_t workspace_bytes, rtgs_stream_t stream);
 

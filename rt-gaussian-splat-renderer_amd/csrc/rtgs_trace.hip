@@ -2322,18 +2322,22 @@ extern "C" int rtgs_project(const RtgsScene* scene, const RtgsCamera* cam, void*
   return project_impl(scene, cam, workspace, workspace_bytes, stream, true);
 }
 
-// k_bin is one more launch in front of the trace (7 us at c3, 20 us at c5): it pays while the
-// launch covers at least a sixth of the frame's tiles (c3: 1/4 shard 59.7 -> 54.8 us, 1/8 42.4 -> 40.0)
-static bool shard_wants_bins(const RtgsCamera* cam, int32_t local_tiles) {
-  return (int64_t)local_tiles * 6 >= rtgs_num_tiles(cam->width, cam->height);
-}
-
+// Round 5: whether a projection builds the slab bins no longer depends on the SHARD (up to here a shard below a sixth
+// of the frame scanned for itself: k_bin, one more launch in front of the trace, 7 us at c3 and 20 us at c5, did not
+// pay for a lone small launch).  A tile's candidates arrive nearest slab first from its bin; a tile that scans for itself
+// lists its survivors in BATCHES of up to kSlabStep scanned slabs when they do not fit one list, each batch sorted for
+// itself -- another arrival order, and the arrival order decides which of two EXACTLY tied entries a ray composites
+// (the reference's BVH order there is unspecified).  One shard with bins and one without could so differ in a pixel:
+// found by the tile-parallel fuzzer (seed 37424: one pixel of a 100 x 16 frame, 40 000 Gaussians, 8.5e-2 between a
+// merged batch -- bins -- and the same shard rendered alone -- none).  Now every launch of a scene large enough for bins
+// uses them, restricted to the shard's own tiles where the projection is the shard's own (rtgs_shard_frame(s)): a
+// tile's arrival order is a function of scene, camera, frame and tile alone again.  RTGS_TRACE_BINS_OFF remains for
+// experiments.
 extern "C" int rtgs_project_shard(const RtgsScene* scene, const RtgsCamera* cam, int32_t tile_first,
                                   int32_t tile_step, void* workspace, size_t workspace_bytes,
                                   rtgs_stream_t stream) {
   if (!cam || tile_step <= 0 || tile_first < 0) return RTGS_EINVAL;
-  const int32_t local = rtgs_num_local_tiles(cam->width, cam->height, tile_first, tile_step);
-  return project_impl(scene, cam, workspace, workspace_bytes, stream, shard_wants_bins(cam, local));
+  return project_impl(scene, cam, workspace, workspace_bytes, stream, true);
 }
 
 // peel lists: [count per pixel: tiles x 256 int32][index plane][exponent plane][t1 plane], the three planes
@@ -2397,10 +2401,8 @@ static int trace_impl(const RtgsScene* scene, const RtgsCamera* cam, const RtgsT
   if (local > tile_limit) local = tile_limit;
   if (local <= 0) return RTGS_OK;  // a shard with no tiles
   if (!projected) {
-    // (frames batched into one launch: the chip is throughput-bound, and the launch as a whole decides whether k_bin pays)
-    bool want_bins = shard_wants_bins(cam, (int32_t)std::min<int64_t>((int64_t)local * frames, INT32_MAX));
-    if (params->flags & RTGS_TRACE_BINS_ON) want_bins = true;
-    if (params->flags & RTGS_TRACE_BINS_OFF) want_bins = false;
+    // (bins whenever the scene is large enough for them, whatever the shard: see rtgs_project_shard)
+    const bool want_bins = !(params->flags & RTGS_TRACE_BINS_OFF);
     // own_bins (rtgs_shard_frame(s): projection and trace of ONE shard, paired per frame): the bins of the shard's
     // own tiles only.  rtgs_trace keeps whole-frame bins -- a caller may trace other shards from this projection
     const bool listed_ = (params->flags & RTGS_TRACE_TILE_LIST) != 0;

@@ -25,8 +25,8 @@ TRACE_COMPACT = 4
 # (8 and 16 were the two-waves-per-tile form's switches up to ABI v6: retired, the bits are ignored)
 TRACE_TILE_LIST = 32   # the shard is RtgsTraceParams.tile_list / tile_count (an empty list renders nothing)
 TRACE_REGION = 64      # the shard lies inside RtgsTraceParams.region: its projection skips what cannot reach it
-TRACE_BINS_ON = 128    # scheduling only: force / forbid the per-frame slab bins for the call's own projection
-TRACE_BINS_OFF = 256
+TRACE_BINS_ON = 128    # (ignored since round 5: bins are the default for every shard)
+TRACE_BINS_OFF = 256   # experiments: no per-frame slab bins for the call's own projection (exact ties may resolve differently)
 PEEL_FRESH = 1
 
 LIB_PATH = os.environ.get("RTGS_HIP_LIB") or os.path.join(

@@ -772,9 +772,9 @@ class TileParallelRenderer:
             nat.check(lib.rtgs_event_create(ctypes.byref(h)), "rtgs_event_create")
             return h.value
 
-        # RTGS_SHARD_BINS: 1 / 0 force / forbid the per-frame slab bins for this rank's shards, auto (default) leaves
-        # the choice to the library (bins from a sixth of the frame's tiles)
-        flags = nat.TRACE_COMPACT | {"1": nat.TRACE_BINS_ON, "0": nat.TRACE_BINS_OFF}.get(os.environ.get("RTGS_SHARD_BINS", "auto"), 0)
+        # RTGS_SHARD_BINS=0 (experiments): this rank's shards scan the slab bounds themselves instead of reading the
+        # per-frame bins -- exact ties may then resolve differently from a frame rendered with them
+        flags = nat.TRACE_COMPACT | (nat.TRACE_BINS_OFF if os.environ.get("RTGS_SHARD_BINS", "1") == "0" else 0)
         if self._shard is not None:
             order = self._shard["order"]
             params = b.shard_params(self._shard, flags)

@@ -90,7 +90,9 @@ def run_parallel_case(seed):
     return checked, r.local_tiles, total
 
 
-# 9194: the soak's find (a 200 x 1 frame, the camera inside a Gaussian: k_bin wrote through a NULL tile list)
-@pytest.mark.parametrize("seed", [*range(5000, 5040), 9194])
+# the soaks' finds -- 9194: a 200 x 1 frame with a Gaussian across the camera plane (k_bin wrote through a NULL tile
+# list); 37424: a 100 x 16 frame whose tiles list more slabs than one scan batch holds (a shard without bins resolved
+# an exact tie the other way than the merged batch with bins: since then every shard of a large scene uses bins)
+@pytest.mark.parametrize("seed", [*range(5000, 5040), 9194, 37424])
 def test_random_tile_parallel_render_sides(seed):
     run_parallel_case(seed)

@@ -221,6 +221,24 @@ def test_gaussians_across_the_camera_plane_in_a_frame_of_partial_supertiles(size
     assert want["hits"].mean() > 4
 
 
+def test_frame_of_more_tiles_than_the_per_tile_lists_provide_for():
+    # 257 x 257 = 66 049 macro-tiles: more than the 65 536 per-tile slab lists the workspace holds (the tiles then
+    # filter their supertile's bin themselves) and more than 4 096 supertiles of 4 x 4 tiles (the bins become 8 x 8)
+    w, h, n = 4112, 4100, 40_000
+    arrays = synthetic.make_scene(n, w / h, 5153)
+    cam = synthetic.bench_camera(w, h)
+    cam["rotation"] = scenes.quat_axis_angle((0.1, 1.0, 0.3), 0.12)
+    _, _, tracer = U.build(arrays, cam)
+    tracer.sample_all(16)
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(4)
+    pix = np.stack([rng.integers(0, w, 2500), rng.integers(0, h, 2500)], axis=-1).astype(np.int32)
+    pix[:8] = [[0, 0], [w - 1, h - 1], [w - 1, 0], [0, h - 1], [4096, 4096], [4111, 4099], [4104, 17], [9, 4097]]
+    want = c_oracle.render(arrays, cam, 16, pix)
+    U.assert_parity(U.at(tracer.sample_buf, pix), want, "66 049-tile frame")
+    assert want["hits"].mean() > 4
+
+
 def test_very_large_scene_two_outer_scan_steps():
     # Tune<true> scans bounds of 16-slab groups first, 1024 groups per step: more than
     # 1024 * 16 * 64 = 1 048 576 Gaussians takes a second outer step of that two-level scan
