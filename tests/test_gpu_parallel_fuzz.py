@@ -96,3 +96,68 @@ def run_parallel_case(seed):
 @pytest.mark.parametrize("seed", [*range(5000, 5040), 9194, 37424])
 def test_random_tile_parallel_render_sides(seed):
     run_parallel_case(seed)
+
+
+def batch_case(seed):
+    """A random single-GPU FrameBatchRenderer run: scene, image, frames per launch, one or two streams, and a few calls
+    of random pose counts with random positions AND orientations."""
+    import scenes
+    rng = np.random.default_rng(seed)
+    w, h = int(rng.choice([1, 17, 40, 64, 100, 161])), int(rng.choice([1, 16, 40, 90]))
+    n = int(rng.choice([1, 65, 700, 5000, 40_000, 66_000]))
+    arrays = synthetic.make_scene(n, max(w / h, 0.2), seed, sh=bool(rng.random() < 0.3))
+    arrays["scale"] = (arrays["scale"] * np.float32(rng.choice([0.5, 1.0, 3.0]))).astype(np.float32)
+    cam = synthetic.bench_camera(w, h)
+    frames, streams = int(rng.integers(1, 9)), int(rng.choice([1, 2]))
+    p0 = np.asarray(cam["position"], np.float64)
+    calls = []
+    for _ in range(int(rng.integers(1, 5))):
+        k = int(rng.integers(1, frames + 1))
+        calls.append([(tuple(p0 + rng.uniform(-0.4, 0.4, 3)), scenes.quat_axis_angle(rng.normal(size=3), rng.uniform(0, 0.5)))
+                      for _ in range(k)])
+    return dict(arrays=arrays, cam=cam, frames=frames, streams=streams, calls=calls, depth=int(rng.choice([1, 3, 16, 16])))
+
+
+def run_batch_case(seed):
+    from rtgs.parallel import FrameBatchRenderer, HipBackend
+    from rtgs.utils.types import vec3, vec4
+    c = batch_case(seed)
+    scene, camera, _ = U.build(c["arrays"], c["cam"])
+    fb = FrameBatchRenderer(scene, camera, depth=c["depth"], frames=c["frames"], streams=c["streams"])
+    hb = HipBackend(scene, camera, c["depth"])
+    want = hb.alloc(hb.width, hb.height, 3)
+    checked = 0
+    # two-stream form: a call's images stay valid until the call after the next -- check each call's images after the
+    # NEXT call has been queued (what a consumer one batch behind sees), the last one at the end
+    held = None
+    for poses in [*c["calls"], None]:
+        if poses is not None:
+            k = fb.render_frames(poses)
+            now = (fb.images, poses, k)
+        for imgs, ps, k in ([held] if held is not None else []):
+            torch.cuda.synchronize()
+            for i in range(k):
+                camera.position, camera.rotation = vec3(ps[i][0]), vec4(ps[i][1])
+                hb.trace(want, 0, 1, compact=False)
+                torch.cuda.synchronize()
+                assert torch.equal(imgs[i], want), (f"seed {seed}: frame {i} of a call of {k}, frames {c['frames']}, streams "
+                                                    f"{c['streams']}, {hb.width}x{hb.height}, depth {c['depth']}")
+                checked += 1
+        held = now if poses is not None else None
+        if c["streams"] == 1 and held is not None:     # one stream: one set of images, valid until the next call only
+            imgs, ps, k = held
+            torch.cuda.synchronize()
+            for i in range(k):
+                camera.position, camera.rotation = vec3(ps[i][0]), vec4(ps[i][1])
+                hb.trace(want, 0, 1, compact=False)
+                torch.cuda.synchronize()
+                assert torch.equal(imgs[i], want), f"seed {seed}: frame {i} of a call of {k} (one stream)"
+                checked += 1
+            held = None
+    fb.close()
+    return checked
+
+
+@pytest.mark.parametrize("seed", range(6000, 6024))
+def test_random_frame_batches_equal_their_single_frame_renders(seed):
+    assert run_batch_case(seed) > 0

@@ -1,4 +1,5 @@
-"""Soak of tests/test_gpu_parallel_fuzz.py's generator: N seeded random tile-parallel render-side cases.  usage: python tools/fuzz_parallel.py N [first]"""
+"""Soak of tests/test_gpu_parallel_fuzz.py's generator: N seeded random tile-parallel render-side cases.  usage: python tools/fuzz_parallel.py N [first]
+FUZZ_BATCHES=1: run_batch_case (FrameBatchRenderer: every image of every call == its single-frame render) instead."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "rt-gaussian-splat-renderer_amd"), ROOT, os.path.join(ROOT, "tests")]
@@ -10,6 +11,9 @@ for seed in range(first, first + n):
     if os.environ.get("FUZZ_LOG_SEEDS"):
         print(f"seed {seed}", file=sys.stderr, flush=True)      # (a GPU fault ends the process: the last such line names the case)
     try:
+        if os.environ.get("FUZZ_BATCHES"):      # the single-GPU FrameBatchRenderer generator instead
+            frames += F.run_batch_case(seed)
+            continue
         c, local, total = F.run_parallel_case(seed)
         frames += c
         empty += local == 0
