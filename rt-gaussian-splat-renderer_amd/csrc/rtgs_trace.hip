@@ -656,7 +656,7 @@ __global__ __launch_bounds__(256) void k_bin(int32_t nslabs, const float4* __res
       float4 gb[kBinIters];
 #pragma unroll
       for (int it = 0; it < kBinIters; ++it) {
-        const int u = base + it * 256 + tid;
+        const int u = base + (wave * kBinIters + it) * kWave + lane;   // wave-contiguous: the list comes out in item order
         gb[it] = make_float4(kInf, kInf, -kInf, -kInf);
         if (u < ngroups) gb[it] = super_bbox[u];
       }
@@ -680,7 +680,7 @@ __global__ __launch_bounds__(256) void k_bin(int32_t nslabs, const float4* __res
 #pragma unroll
       for (int it = 0; it < kBinIters; ++it) {
         if ((gm[it] >> lane) & 1ull)
-          s_grp[off + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(gm[it] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)gm[it], 0u))] = base + it * 256 + tid;
+          s_grp[off + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(gm[it] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)gm[it], 0u))] = base + (wave * kBinIters + it) * kWave + lane;
         off += __popcll(gm[it]);
       }
     }
@@ -693,7 +693,7 @@ __global__ __launch_bounds__(256) void k_bin(int32_t nslabs, const float4* __res
     int sid[kBinIters];
 #pragma unroll
     for (int it = 0; it < kBinIters; ++it) {
-      const int item = base + it * 256 + tid;
+      const int item = base + (wave * kBinIters + it) * kWave + lane;
       int sl = item;
       if constexpr (kGroups) sl = item < nitems ? s_grp[item / kSuper] * kSuper + (item % kSuper) : nslabs;
       sid[it] = sl;
@@ -1138,7 +1138,7 @@ __global__ __launch_bounds__(kTraceBlock,
     float4 gbb[kSlabIters];
 #pragma unroll
     for (int it = 0; it < kSlabIters; ++it) {
-      const int u = ub + it * kBlock + tid;
+      const int u = ub + (wave * kSlabIters + it) * kWave + lane;
       gbb[it] = make_float4(kInf, kInf, -kInf, -kInf);
       if (u < nsuper) gbb[it] = super_bbox[u];
     }
@@ -1161,7 +1161,7 @@ __global__ __launch_bounds__(kTraceBlock,
     }
 #pragma unroll
     for (int it = 0; it < kSlabIters; ++it) {
-      if ((um[it] >> lane) & 1ull) s_super[uoff + below(um[it])] = ub + it * kBlock + tid;
+      if ((um[it] >> lane) & 1ull) s_super[uoff + below(um[it])] = ub + (wave * kSlabIters + it) * kWave + lane;
       uoff += __popcll(um[it]);
     }
     __syncthreads();
@@ -1184,7 +1184,13 @@ __global__ __launch_bounds__(kTraceBlock,
     int slid[kSlabIters];
 #pragma unroll
     for (int it = 0; it < kSlabIters; ++it) {
-      const int item = sbase + it * kBlock + tid;
+      // Every wave takes kSlabIters * 64 CONSECUTIVE items, so that the survivors -- listed wave by wave, step by step --
+      // come out in item order: a bin's order (nearest slab first) survives the filter.  (Up to round 5 step `it` of
+      // thread `tid` took item it * 256 + tid: wave 0 listed items 0-63 and 256-319 before wave 1's 64-127 -- harmless
+      // where the list is sorted afterwards, but a tile that falls back to its supertile's bin met its slabs in a
+      // permuted order: farther candidates first, and an exact tie across two slabs resolved against the list's order,
+      // which the tie fix-up's find_next goes by.  Found with coloured twins, tools/debug_twin_seed.py 50062.)
+      const int item = sbase + (wave * kSlabIters + it) * kWave + lane;
       int sl = item;
       if (binned) sl = item < nitems ? bin[item] : nslabs;          // listed nearest first by k_bin
       else if constexpr (kTwo) sl = item < nitems ? s_super[item / kSuper] * kSuper + (item % kSuper) : nslabs;
@@ -1268,14 +1274,22 @@ __global__ __launch_bounds__(kTraceBlock,
     // expansion and tracing, and the list order -- region by region, slab by slab, lane by lane
     // -- is a function of the tile alone (equal t1 keys resolve identically on every run, for
     // every sharding and in both workgroup forms).
-    const int share = (scnt + kRegions - 1) / kRegions;
-    int pos = min(scnt, wave * share);
-    const int pend = wave < kRegions ? min(scnt, (wave + 1) * share) : pos;
+    // Rounds keep that order too (round 5): a round ends at the FIRST region that filled up -- what the regions behind
+    // it have expanded waits for the next round, which deals the slabs from there on out again -- so the candidates
+    // always arrive in the slab list's order.  (Up to here every region went on where IT had stopped: round 1 = the
+    // head of every share, round 2 = the tails, and a Gaussian of the second share could arrive before one of the first
+    // share's tail.  Only exact ties see the order: the tie fix-up's find_next resolves them by the list's order, so a
+    // ray's 13th entry could be one twin in a one-pass trace and the other in the 13th single-peel launch -- found with
+    // coloured twins in tiles of > 512 survivors, tests/test_gpu_parallel_fuzz.py::twin_paths_case.)
+    int gpos = 0;   // slabs of the list handed to a finished round so far (identical in every thread)
     for (;;) {
 #if RTGS_STAMPS
       t_mark = __builtin_amdgcn_s_memtime();
       ++c_rounds;
 #endif
+      const int share = (scnt - gpos + kRegions - 1) / kRegions;
+      int pos = min(scnt, gpos + wave * share);
+      const int pend = wave < kRegions ? min(scnt, gpos + (wave + 1) * share) : pos;
       int rcnt = 0;   // survivors this wave has listed in its region this round (wave-uniform)
       while (pos < pend) {
         // kExpand slabs in flight: one lane per Gaussian, 16-B bounds, coalesced
@@ -1310,14 +1324,16 @@ __global__ __launch_bounds__(kTraceBlock,
         }
         if (full) break;
       }
-      if (lane == 0 && wave < kRegions) { s_rcnt[wave] = rcnt; s_rmore[wave] = pos < pend ? 1 : 0; }
+      if (lane == 0 && wave < kRegions) { s_rcnt[wave] = rcnt; s_rmore[wave] = pos < pend ? pos + 1 : 0; }
       __syncthreads();
       int rc[kRegions];
       int more = 0, total = 0;
 #pragma unroll
       for (int r = 0; r < kRegions; ++r) {
-        rc[r] = __builtin_amdgcn_readfirstlane(s_rcnt[r]);   // wave-uniform: SGPRs
-        more |= __builtin_amdgcn_readfirstlane(s_rmore[r]);
+        // (wave-uniform: SGPRs.)  s_rmore: 0 = the region took its whole share, else 1 + the slab it stopped at
+        rc[r] = more ? 0 : __builtin_amdgcn_readfirstlane(s_rcnt[r]);   // behind the first full region: next round
+        const int stop = __builtin_amdgcn_readfirstlane(s_rmore[r]);
+        if (!more && stop) { more = 1; gpos = stop - 1; }
         total += rc[r];
       }
 #if RTGS_STAMPS

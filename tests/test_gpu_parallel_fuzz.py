@@ -16,6 +16,22 @@ from rtgs import synthetic
 pytestmark = pytest.mark.gpu
 
 
+def add_coloured_twins(arrays, rng, chance=0.3):
+    """With probability `chance`: a random share of the Gaussians stored a second time with ANOTHER colour -- rays that
+    hit a pair see two entries tied exactly, and which of them is composited (the reference: its BVH's order,
+    unspecified; here: the first to arrive) shows in the pixel.  Every path that renders a tile must therefore meet
+    its candidates in the same order, or the bitwise comparisons of this file fail."""
+    if rng.random() >= chance:
+        return arrays
+    n0 = arrays["position"].shape[0]
+    pick = np.nonzero(rng.random(n0) < rng.uniform(0.05, 0.5))[0]
+    if pick.size == 0:
+        return arrays
+    out = {k: (None if v is None else np.ascontiguousarray(np.concatenate([v, v[pick]]))) for k, v in arrays.items()}
+    out["color"][n0:] = rng.random((pick.size, 3)).astype(np.float32)
+    return out
+
+
 def parallel_case(seed):
     rng = np.random.default_rng(seed)
     w, h = int(rng.choice([1, 17, 33, 64, 100, 161, 200])), int(rng.choice([1, 16, 40, 90, 128]))
@@ -44,6 +60,7 @@ def parallel_case(seed):
         portions.append(k)
         left -= k
     depth = int(rng.choice([1, 3, 16, 16, 16]))
+    arrays = add_coloured_twins(arrays, rng)
     return dict(arrays=arrays, cam=cam, world=world, rank=rank, landing=landing, batch=batch, in_flight=in_flight,
                 deal=str(deal), shares=shares, poses=poses, portions=portions, depth=depth)
 
@@ -115,7 +132,9 @@ def batch_case(seed):
         k = int(rng.integers(1, frames + 1))
         calls.append([(tuple(p0 + rng.uniform(-0.4, 0.4, 3)), scenes.quat_axis_angle(rng.normal(size=3), rng.uniform(0, 0.5)))
                       for _ in range(k)])
-    return dict(arrays=arrays, cam=cam, frames=frames, streams=streams, calls=calls, depth=int(rng.choice([1, 3, 16, 16])))
+    depth = int(rng.choice([1, 3, 16, 16]))
+    arrays = add_coloured_twins(arrays, rng)
+    return dict(arrays=arrays, cam=cam, frames=frames, streams=streams, calls=calls, depth=depth)
 
 
 def run_batch_case(seed):
@@ -161,3 +180,56 @@ def run_batch_case(seed):
 @pytest.mark.parametrize("seed", range(6000, 6024))
 def test_random_frame_batches_equal_their_single_frame_renders(seed):
     assert run_batch_case(seed) > 0
+
+
+def twin_paths_case(seed):
+    """A scene with coloured twins (always) under a random camera, for the RayTracer's own paths."""
+    import scenes
+    rng = np.random.default_rng(seed)
+    w, h = int(rng.integers(8, 200)), int(rng.integers(8, 120))
+    n = int(rng.choice([300, 5000, 33_000, 40_000, 66_000]))
+    arrays = synthetic.make_scene(n, w / h, seed, sh=bool(rng.random() < 0.25))
+    arrays["scale"] = (arrays["scale"] * np.float32(rng.choice([0.5, 1.0, 3.0]))).astype(np.float32)
+    arrays = add_coloured_twins(arrays, rng, chance=1.0)
+    cam = synthetic.bench_camera(w, h)
+    cam["position"] = scenes.f32_tuple(np.asarray(cam["position"]) + rng.normal(0, 0.3, 3))
+    cam["rotation"] = scenes.quat_axis_angle(rng.normal(size=3), rng.uniform(0, 0.4))
+    return arrays, cam, int(rng.choice([1, 2, 5, 16, 16, 20])), int(rng.choice([2, 3, 5, 8]))
+
+
+def run_twin_paths_case(seed):
+    """sample_all == the frame traced in `world` shards, bit for bit; == the listed one-peel-per-call sample() loop and
+    the single-peel sample_step loop to rounding (they composite in another kernel: a tie resolved the other way
+    would show as a whole colour)."""
+    import rtgs
+    arrays, cam, depth, world = twin_paths_case(seed)
+    w, h = cam["width"], cam["height"]
+
+    def tracer():
+        return rtgs.RayTracer((w, h), rtgs.Scene.from_arrays(**arrays),
+                              rtgs.Camera(cam["position"], cam["rotation"], (w, h), (cam["fx"], cam["fy"])))
+    a = tracer()
+    a.sample_all(depth)
+    b = tracer()
+    if depth <= nat.MAX_DEPTH:
+        for r in range(world):
+            b.trace(depth, tile_first=r, tile_step=world, state=False)
+        torch.cuda.synchronize()
+        assert torch.equal(a.sample_buf, b.sample_buf), f"seed {seed}: {world} shards differ from the whole frame"
+    c = tracer()
+    for _ in range(depth):
+        c.sample(depth)
+    d = tracer()
+    d._use_lists = False
+    for _ in range(depth):
+        d.sample(depth)
+    torch.cuda.synchronize()
+    for name, t in (("listed sample() loop", c), ("single-peel sample() loop", d)):
+        gap = float((a.sample_buf - t.sample_buf).abs().max())
+        assert gap <= 2e-5, f"seed {seed}: the {name} differs from sample_all by {gap:.2e} (depth {depth}, {w}x{h})"
+    return w * h
+
+
+@pytest.mark.parametrize("seed", range(7000, 7016))
+def test_exact_ties_resolve_alike_on_every_path(seed):
+    run_twin_paths_case(seed)

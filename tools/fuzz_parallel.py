@@ -1,5 +1,5 @@
 """Soak of tests/test_gpu_parallel_fuzz.py's generator: N seeded random tile-parallel render-side cases.  usage: python tools/fuzz_parallel.py N [first]
-FUZZ_BATCHES=1: run_batch_case (FrameBatchRenderer: every image of every call == its single-frame render) instead."""
+FUZZ_TWINS=1: run_twin_paths_case (coloured twins: sample_all == shards == both sample() loops); FUZZ_BATCHES=1: run_batch_case (FrameBatchRenderer: every image of every call == its single-frame render) instead."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "rt-gaussian-splat-renderer_amd"), ROOT, os.path.join(ROOT, "tests")]
@@ -13,6 +13,9 @@ for seed in range(first, first + n):
     try:
         if os.environ.get("FUZZ_BATCHES"):      # the single-GPU FrameBatchRenderer generator instead
             frames += F.run_batch_case(seed)
+            continue
+        if os.environ.get("FUZZ_TWINS"):        # coloured twins through the RayTracer's own paths (counts pixels)
+            frames += F.run_twin_paths_case(seed)
             continue
         c, local, total = F.run_parallel_case(seed)
         frames += c
