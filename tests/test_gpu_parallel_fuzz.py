@@ -188,6 +188,11 @@ def twin_paths_case(seed):
     rng = np.random.default_rng(seed)
     w, h = int(rng.integers(8, 200)), int(rng.integers(8, 120))
     n = int(rng.choice([300, 5000, 33_000, 40_000, 66_000]))
+    if n > 40_000:
+        # (more than 1024 slabs: on a frame of a few supertiles one of them would list more slabs than a bin holds, and
+        # a tile that then scans ALL slabs in batches meets them in an order of its own -- the one documented case in
+        # which an exact tie may resolve differently in the tie fix-up)
+        w, h = int(rng.integers(256, 420)), int(rng.integers(256, 420))
     arrays = synthetic.make_scene(n, w / h, seed, sh=bool(rng.random() < 0.25))
     arrays["scale"] = (arrays["scale"] * np.float32(rng.choice([0.5, 1.0, 3.0]))).astype(np.float32)
     arrays = add_coloured_twins(arrays, rng, chance=1.0)
