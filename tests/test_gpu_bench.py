@@ -19,6 +19,7 @@ def _run(args, env=None, timeout=900):
     e = dict(os.environ)
     e.pop("WORLD_SIZE", None)
     e.pop("RANK", None)
+    e.setdefault("RTGS_TRACE_PHASES", "1")     # a hang or a timeout then names the phase every rank stood in (stderr)
     e.update(env or {})
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
                          timeout=timeout, env=e, cwd=ROOT)
@@ -30,7 +31,7 @@ def _run(args, env=None, timeout=900):
 def test_bare_bench_with_two_ranks_starts_them_itself_and_verifies(extra, env):
     out, line = _run(["--gpus", "2", "--backend", "gloo", "--same-device", "--steps", "6", "--warmup", "2",
                       "--config", "c2", *extra], env)
-    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.returncode == 0, out.stderr[-8000:]
     assert line is not None and line["n_gpus"] == 2 and line["verified"] is True
     assert line["value"] > 0 and line["steps"] == 6 and line["timed_s"] >= 1.0
     pr = line["per_rank"]
