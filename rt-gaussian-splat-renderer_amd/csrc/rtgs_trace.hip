@@ -1010,7 +1010,7 @@ __global__ __launch_bounds__(kTraceBlock,
   // slabs one wave has in flight: more only pay where latency counts (the two-wave form's small launches)
   constexpr int kExpand = TN::kExpand;
   static_assert(kRegionCap >= kSlab, "a region must hold one whole slab");
-  __shared__ int s_rcnt[kRegions], s_rmore[kRegions];
+  __shared__ int s_rcnt[kRegions], s_rmore[kRegions], s_rfirst;
   constexpr int kSuperStep = kSlabIters * kBlock;   // slab groups scanned per outer step
   constexpr bool kTwo = kBig;   // two-level slab scan (small scenes: c3 0.260 vs 0.261 ms flat, one barrier more)
   static_assert(kSuperInts == (kTwo ? kSuperStep : 1), "group list size");
@@ -1274,23 +1274,37 @@ __global__ __launch_bounds__(kTraceBlock,
     // expansion and tracing, and the list order -- region by region, slab by slab, lane by lane
     // -- is a function of the tile alone (equal t1 keys resolve identically on every run, for
     // every sharding and in both workgroup forms).
-    // Rounds keep that order too (round 5): a round ends at the FIRST region that filled up -- what the regions behind
-    // it have expanded waits for the next round, which deals the slabs from there on out again -- so the candidates
-    // always arrive in the slab list's order.  (Up to here every region went on where IT had stopped: round 1 = the
-    // head of every share, round 2 = the tails, and a Gaussian of the second share could arrive before one of the first
-    // share's tail.  Only exact ties see the order: the tie fix-up's find_next resolves them by the list's order, so a
-    // ray's 13th entry could be one twin in a one-pass trace and the other in the 13th single-peel launch -- found with
-    // coloured twins in tiles of > 512 survivors, tests/test_gpu_parallel_fuzz.py::twin_paths_case.)
-    int gpos = 0;   // slabs of the list handed to a finished round so far (identical in every thread)
+    // Rounds keep that order too (round 5): a round TRACES the regions up to the first one that filled up before its
+    // share was done; the regions behind it keep what they have expanded and wait (nothing is expanded twice), the full
+    // one goes on with its share in the next round -- so the candidates always arrive in the slab list's order.  (Up to
+    // here every round traced every region: round 1 = the head of every share, round 2 = the tails, and a Gaussian of the
+    // second share could arrive before one of the first share's tail.  Only exact ties see the order: the tie fix-up's
+    // find_next resolves them by the list's order, so a ray's 13th entry could be one twin in a one-pass trace and the
+    // other in the 13th single-peel launch -- found with coloured twins in tiles of > 512 survivors,
+    // tests/test_gpu_parallel_fuzz.py::twin_paths_case.)
+    const int share = (scnt + kRegions - 1) / kRegions;
+    int pos = min(scnt, wave * share);
+    const int pend = wave < kRegions ? min(scnt, (wave + 1) * share) : pos;
+    // (which region goes on is kept in LDS, not in a register: two more scalars alive through the candidate loop cost the
+    // c3 form 2 % -- its SGPRs spill as it is.  After a batch's first round the ONLY region that expands is the one
+    // that filled up: the ones before it are finished, the ones behind it still hold what they expanded in round one.
+    // (A survivor list of 1024 instead of 512 -- fewer rounds -- changed nothing at c3 / cap / c2; 2048 costs a workgroup per CU.)
+    // What this cost and why (A/B of library builds, gpurun_out/ab_*.txt): the first version was 1.8 % slower at c3 and
+    // c2 -- not the rounds: the region counts, read under the new conditions, had become eight dependent 4-B LDS reads
+    // with a wait each, ahead of the first chunk's loads on every tile's critical path.  Read unconditionally (two
+    // 16-B reads as before) and combined as integer masks: k_trace as fast as before, the c3 frame within 0.8 %.)
+    int more = 0;
     for (;;) {
 #if RTGS_STAMPS
       t_mark = __builtin_amdgcn_s_memtime();
       ++c_rounds;
 #endif
-      const int share = (scnt - gpos + kRegions - 1) / kRegions;
-      int pos = min(scnt, gpos + wave * share);
-      const int pend = wave < kRegions ? min(scnt, gpos + (wave + 1) * share) : pos;
-      int rcnt = 0;   // survivors this wave has listed in its region this round (wave-uniform)
+      // (a batch's first round -- for nearly every tile its only one -- reads no state: `more`, which the loop carries
+      // anyway, says whether this is a later round)
+      int first = 0;
+      if (__builtin_expect(more != 0, 0)) first = __builtin_amdgcn_readfirstlane(s_rfirst);   // the region that goes on
+      if (!more || wave == first) {
+      int rcnt = 0;   // survivors this wave lists in its region this round (wave-uniform)
       while (pos < pend) {
         // kExpand slabs in flight: one lane per Gaussian, 16-B bounds, coalesced
         float4 gb[kExpand];
@@ -1314,7 +1328,7 @@ __global__ __launch_bounds__(kTraceBlock,
             n_exp += kWave;
 #endif
             if (rcnt + c > kRegionCap) {
-              full = true;   // this slab opens the next round
+              full = true;   // this slab opens the region's next round
             } else {
               if (keep) s_idx[wave * kRegionCap + rcnt + below(gm)] = gbase[q] + lane;
               rcnt += c;
@@ -1324,17 +1338,37 @@ __global__ __launch_bounds__(kTraceBlock,
         }
         if (full) break;
       }
-      if (lane == 0 && wave < kRegions) { s_rcnt[wave] = rcnt; s_rmore[wave] = pos < pend ? pos + 1 : 0; }
+      if (lane == 0 && wave < kRegions) { s_rcnt[wave] = rcnt; s_rmore[wave] = pos < pend ? 1 : 0; }
+      }
       __syncthreads();
       int rc[kRegions];
-      int more = 0, total = 0;
+      int total = 0;
+      more = 0;
+      {
+        // (all eight values first, unconditionally -- two 16-B LDS reads as before; read under the conditions below
+        // they became eight dependent 4-B reads, each with its own wait: 2 % of a c3 frame)
+        int cnt_r[kRegions], more_r[kRegions];
 #pragma unroll
-      for (int r = 0; r < kRegions; ++r) {
-        // (wave-uniform: SGPRs.)  s_rmore: 0 = the region took its whole share, else 1 + the slab it stopped at
-        rc[r] = more ? 0 : __builtin_amdgcn_readfirstlane(s_rcnt[r]);   // behind the first full region: next round
-        const int stop = __builtin_amdgcn_readfirstlane(s_rmore[r]);
-        if (!more && stop) { more = 1; gpos = stop - 1; }
-        total += rc[r];
+        for (int r = 0; r < kRegions; ++r) {
+          cnt_r[r] = __builtin_amdgcn_readfirstlane(s_rcnt[r]);     // wave-uniform: SGPRs
+          more_r[r] = __builtin_amdgcn_readfirstlane(s_rmore[r]);
+        }
+        // regions below `first` are finished, regions behind the first full one wait.  (Integer masks: as bools the
+        // compiler took these wave-uniform values through VGPRs and 60 instructions -- ahead of the first chunk's
+        // loads, on every tile's critical path)
+        int last_r = 0;
+#pragma unroll
+        for (int r = 0; r < kRegions; ++r) {
+          const int on = (r >= first ? 1 : 0) & (more ^ 1);
+          rc[r] = cnt_r[r] & -on;
+          const int full = on & (more_r[r] != 0 ? 1 : 0);
+          last_r |= r & -full;      // (at most one region is `full`)
+          more |= full;
+          total += rc[r];
+        }
+        // (every wave stores the same value; the next round reads it behind this round's closing barrier, and every
+        // reader of the old value is past the barrier above)
+        if (more && lane == 0) s_rfirst = last_r;
       }
 #if RTGS_STAMPS
       if (st[2] == 0) st[2] = __builtin_amdgcn_s_memtime();
